@@ -1,0 +1,270 @@
+"""ctypes binding of include/gtop.h (the C-ABI of libgtop_hip.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgtop_hip.so")
+
+GTOP_F64, GTOP_F32 = 0, 1
+_STATUS = {0: "GTOP_OK", 1: "GTOP_ERR_INVALID", 2: "GTOP_ERR_HIP", 3: "GTOP_ERR_NO_DEVICE",
+           4: "GTOP_ERR_STATE"}
+
+
+class GtopError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__(f"{_STATUS.get(code, code)}: {msg}")
+
+
+class GtopParams(C.Structure):
+    """gtop_params — the ROS parameters the callback reads
+    (src/grad_traj_optimizer.cpp:5-32 of the reference) + step + enable_dyn."""
+    _fields_ = [
+        ("ws", C.c_double), ("wc", C.c_double),
+        ("alpha", C.c_double), ("r", C.c_double), ("d0", C.c_double),
+        ("alpha_v", C.c_double), ("r_v", C.c_double), ("v0", C.c_double),
+        ("alpha_a", C.c_double), ("r_a", C.c_double), ("a0", C.c_double),
+        ("step", C.c_int32), ("enable_dyn", C.c_int32),
+    ]
+
+
+# launch/opti_node.launch:3-28 of the reference — the only parameter set whose
+# names match what the ctor reads.
+OPTI_NODE_PARAMS = dict(ws=1.0, wc=5.0, alpha=10.0, r=0.5, d0=0.8,
+                        alpha_v=0.0, r_v=1.5, v0=2.5, alpha_a=0.0, r_a=1.5, a0=3.5,
+                        step=2, enable_dyn=0)
+
+_lib = None
+
+
+def library_path():
+    return _SO
+
+
+def _preload_torch_hip_runtime():
+    """One process must hold ONE HIP runtime.  The PyTorch-ROCm wheel bundles
+    its own libamdhip64.so (SONAME libamdhip64.so.7, the name libgtop_hip.so
+    needs): if libgtop_hip.so were loaded first it would pull /opt/rocm's copy,
+    a later `import torch` would add the bundled one, and whichever initialises
+    second sees "no ROCm-capable device".  So when torch is installed, map its
+    copy first (by path, without importing torch); the loader then resolves our
+    NEEDED entry to it by SONAME, and torch finds it already loaded."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def load_library():
+    """Load libgtop_hip.so.  Raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(
+            f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C grad_traj_optimization_amd/csrc` — there is no CPU fallback")
+    _preload_torch_hip_runtime()
+    L = C.CDLL(_SO)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    sig = {
+        "gtop_abi_version": (C.c_int, []),
+        "gtop_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "gtop_destroy": (C.c_int, [vp]),
+        "gtop_last_error": (C.c_char_p, [vp]),
+        "gtop_set_params": (C.c_int, [vp, C.POINTER(GtopParams)]),
+        "gtop_set_sdf": (C.c_int, [vp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double]),
+        "gtop_set_sdf_device": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double]),
+        "gtop_init_sdf_map": (C.c_int, [vp, dp, dp, C.c_double]),
+        "gtop_update_sdf_map": (C.c_int, [vp, dp, C.c_int]),
+        "gtop_get_sdf": (C.c_int, [vp, dp, ip]),
+        "gtop_set_problem": (C.c_int, [vp, C.c_int, C.c_int, dp, C.c_int, dp]),
+        "gtop_eval_batch": (C.c_int, [vp, C.c_int, dp, dp, dp]),
+        "gtop_cost_nlopt": (C.c_double, [C.c_uint, dp, dp, vp]),
+        "gtop_eval_device": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]),
+        "gtop_get_stats": (C.c_int, [vp, C.POINTER(C.c_int64), dp]),
+        "gtop_reset_stats": (C.c_int, [vp]),
+        "gtop_get_cost_curve": (C.c_int, [vp, dp, dp, C.c_int, ip]),
+        "gtop_clear_cost_curve": (C.c_int, [vp]),
+        "gtop_set_waves_per_block": (C.c_int, [vp, C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class GtopContext:
+    """One gtop_ctx (one per host thread / HIP stream)."""
+
+    def __init__(self, device=0, params=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.gtop_create(C.byref(h), int(device))
+        if rc != 0:
+            raise GtopError(rc, self._L.gtop_last_error(None).decode()
+                            + " — a gfx950 GPU is required; there is no CPU fallback")
+        self._h = h
+        self.device = int(device)
+        self.set_params(**(params or {}))
+
+    # -- helpers --
+    def _chk(self, rc):
+        if rc != 0:
+            raise GtopError(rc, self._L.gtop_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gtop_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration --
+    def set_params(self, **kw):
+        d = dict(OPTI_NODE_PARAMS)
+        d.update(kw)
+        self.params = d
+        p = GtopParams(**d)
+        self._chk(self._L.gtop_set_params(self._h, C.byref(p)))
+
+    def set_sdf(self, dist, grid, origin, resolution, map_size=None):
+        dist = _f64(dist).reshape(-1)
+        nx, ny, nz = (int(g) for g in grid)
+        assert dist.size == nx * ny * nz
+        ms = _p(_f64(map_size)) if map_size is not None else None
+        self._chk(self._L.gtop_set_sdf(self._h, _p(dist), nx, ny, nz, _p(_f64(origin)), ms, float(resolution)))
+        self.grid = (nx, ny, nz)
+
+    def set_sdf_device(self, tensor, grid, origin, resolution, map_size=None):
+        import torch
+        dtype = {torch.float64: GTOP_F64, torch.float32: GTOP_F32}[tensor.dtype]
+        nx, ny, nz = (int(g) for g in grid)
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == nx * ny * nz
+        ms = _p(_f64(map_size)) if map_size is not None else None
+        self._chk(self._L.gtop_set_sdf_device(self._h, dtype, C.c_void_p(tensor.data_ptr()), nx, ny, nz,
+                                              _p(_f64(origin)), ms, float(resolution)))
+        self._sdf_keepalive = tensor
+        self.grid = (nx, ny, nz)
+
+    def init_sdf_map(self, map_size, origin, resolution):
+        self._chk(self._L.gtop_init_sdf_map(self._h, _p(_f64(map_size)), _p(_f64(origin)), float(resolution)))
+        g = (C.c_int * 3)()
+        self._chk(self._L.gtop_get_sdf(self._h, None, g))
+        self.grid = tuple(g)
+
+    def update_sdf_map(self, pts):
+        pts = _f64(pts).reshape(-1, 3)
+        self._chk(self._L.gtop_update_sdf_map(self._h, _p(pts), pts.shape[0]))
+
+    def get_sdf(self):
+        g = (C.c_int * 3)()
+        self._chk(self._L.gtop_get_sdf(self._h, None, g))
+        out = np.empty(g[0] * g[1] * g[2])
+        self._chk(self._L.gtop_get_sdf(self._h, _p(out), g))
+        return out.reshape(tuple(g))
+
+    def set_problem(self, T, Df):
+        Df = _f64(Df)
+        B = Df.size // 18
+        T = _f64(T)
+        if T.ndim == 2:
+            m, stride = T.shape[1], T.shape[1]
+            assert T.shape[0] == B
+        else:
+            m, stride = T.shape[0], 0
+        self._chk(self._L.gtop_set_problem(self._h, B, m, _p(T), stride, _p(Df)))
+        self.B, self.m = B, m
+
+    def set_waves_per_block(self, waves):
+        self._chk(self._L.gtop_set_waves_per_block(self._h, int(waves)))
+
+    # -- evaluation --
+    def eval_batch(self, x):
+        """Host arrays in, host arrays out (fp64, PCIe copies included)."""
+        x = _f64(x)
+        B = x.shape[0]
+        n = 9 * (self.m - 1)
+        assert x.shape == (B, n)
+        cost = np.empty(B)
+        grad = np.empty((B, n))
+        self._chk(self._L.gtop_eval_batch(self._h, B, _p(x), _p(cost), _p(grad)))
+        return cost, grad
+
+    def cost_nlopt(self, x, want_grad=True):
+        """The nlopt_func-shaped entry point on trajectory 0."""
+        x = _f64(x)
+        g = np.empty_like(x) if want_grad else None
+        c = self._L.gtop_cost_nlopt(x.size, _p(x), _p(g) if want_grad else None, self._h)
+        if not np.isfinite(c):
+            raise GtopError(1, self._L.gtop_last_error(self._h).decode())
+        return c, g
+
+    def eval_device(self, x, Df, T, cost=None, grad=None, stream=None):
+        """torch CUDA tensors in HBM; launches on `stream` (default: torch's
+        current stream) and returns without synchronising."""
+        import torch
+        dtype = {torch.float64: GTOP_F64, torch.float32: GTOP_F32}[x.dtype]
+        B, n = x.shape
+        m = n // 9 + 1
+        assert n == 9 * (m - 1) and Df.numel() == B * 18
+        stride = m if T.dim() == 2 else 0
+        assert T.numel() == (B * m if stride else m)
+        for t in (x, Df, T):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == x.dtype
+        if cost is None:
+            cost = torch.empty(B, dtype=x.dtype, device=x.device)
+        if grad is None:
+            grad = torch.empty(B, n, dtype=x.dtype, device=x.device)
+        assert cost.is_contiguous() and grad.is_contiguous() and cost.numel() == B and grad.numel() == B * n
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._chk(self._L.gtop_eval_device(self._h, dtype, B, m, C.c_void_p(x.data_ptr()),
+                                           C.c_void_p(Df.data_ptr()), C.c_void_p(T.data_ptr()), stride,
+                                           C.c_void_p(cost.data_ptr()), C.c_void_p(grad.data_ptr()),
+                                           C.c_void_p(stream)))
+        return cost, grad
+
+    # -- bookkeeping --
+    def stats(self):
+        it = C.c_int64()
+        tt = C.c_double()
+        self._chk(self._L.gtop_get_stats(self._h, C.byref(it), C.byref(tt)))
+        return it.value, tt.value
+
+    def reset_stats(self):
+        self._chk(self._L.gtop_reset_stats(self._h))
+
+    def cost_curve(self):
+        cnt = C.c_int()
+        self._chk(self._L.gtop_get_cost_curve(self._h, None, None, 0, C.byref(cnt)))
+        c = np.empty(cnt.value)
+        t = np.empty(cnt.value)
+        if cnt.value:
+            self._chk(self._L.gtop_get_cost_curve(self._h, _p(c), _p(t), cnt.value, C.byref(cnt)))
+        return c, t
+
+    def clear_cost_curve(self):
+        self._chk(self._L.gtop_clear_cost_curve(self._h))

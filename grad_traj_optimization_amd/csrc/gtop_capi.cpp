@@ -1,0 +1,470 @@
+// gtop_capi.cpp — implementation of the C-ABI in include/gtop.h on top of the
+// gfx950 kernels.  Host-side only: owns device buffers, fills kernel
+// arguments, launches.  There is deliberately no CPU code path: without a
+// gfx950 device every entry point fails (GTOP_ERR_NO_DEVICE).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gtop.h"
+#include "gtop_kernels.h"
+
+#define GTOP_ABI_VERSION 1
+
+struct gtop_ctx {
+  int device = 0;
+  std::string err;
+  hipStream_t stream = nullptr;   // used by the host-pointer entry points
+
+  gtop_params prm{};
+  bool have_params = false;
+
+  GtopGrid grid{};
+  bool have_grid = false;
+  double *sdf64 = nullptr;
+  float *sdf32 = nullptr;
+  bool own64 = false, own32 = false;
+  size_t sdf_cap64 = 0, sdf_cap32 = 0;   // elements, for owned buffers
+
+  // ESDF construction workspace
+  uint8_t *occ = nullptr;
+  double *tmp1 = nullptr, *tmp2 = nullptr, *zws = nullptr, *d_pts = nullptr;
+  int *vws = nullptr;
+  size_t cap_occ = 0, cap_tmp1 = 0, cap_tmp2 = 0, cap_vws = 0, cap_zws = 0, pts_cap = 0;
+
+  // problem set by gtop_set_problem
+  int B = 0, m = 0, t_stride = 0;
+  double *d_T = nullptr, *d_Df = nullptr, *d_x = nullptr, *d_cost = nullptr, *d_grad = nullptr;
+  size_t cap_T = 0, cap_Df = 0, cap_x = 0, cap_grad = 0, cap_cost = 0;
+
+  int waves = 0;   // 0 = auto
+
+  // bookkeeping of the callback (grad_traj_optimizer.cpp:284, :436, :439-447)
+  int64_t iter_num = 0;
+  double total_time = 0.0;
+  std::vector<double> vec_cost, vec_time;
+  std::chrono::steady_clock::time_point time_start = std::chrono::steady_clock::now();
+};
+
+namespace {
+
+// error text of a failed gtop_create (there is no context to hold it yet)
+thread_local std::string g_create_err;
+
+int fail(gtop_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  else g_create_err = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(ctx, GTOP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+int ensure(gtop_ctx *c, T **p, size_t *cap, size_t need) {
+  if (need <= *cap && *p) return GTOP_OK;
+  if (*p) HIPCHK(c, hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void **>(p), need * sizeof(T)));
+  *cap = need;
+  return GTOP_OK;
+}
+
+int fill_grid(gtop_ctx *c, int nx, int ny, int nz, const double origin[3], const double *map_size,
+              double res) {
+  if (!origin || nx < 2 || ny < 2 || nz < 2 || !(res > 0.0))
+    return fail(c, GTOP_ERR_INVALID, "SDF geometry: need origin, grid >= 2 per axis, resolution > 0");
+  if ((double)nx * ny * nz >= 2147483648.0)
+    return fail(c, GTOP_ERR_INVALID, "SDF geometry: nx*ny*nz must be < 2^31");
+  GtopGrid &g = c->grid;
+  g.nx = nx; g.ny = ny; g.nz = nz;
+  g.res = res;
+  g.res_inv = 1 / res;   // sdf_map.cpp:7
+  const int gs[3] = {nx, ny, nz};
+  for (int i = 0; i < 3; ++i) {
+    g.origin[i] = origin[i];
+    g.min_range[i] = origin[i];                                            // sdf_map.cpp:11
+    g.max_range[i] = origin[i] + (map_size ? map_size[i] : gs[i] * res);   // sdf_map.cpp:12
+  }
+  c->have_grid = true;
+  return GTOP_OK;
+}
+
+void release_sdf(gtop_ctx *c) {
+  if (c->own64 && c->sdf64) (void)hipFree(c->sdf64);
+  if (c->own32 && c->sdf32) (void)hipFree(c->sdf32);
+  c->sdf64 = nullptr;
+  c->sdf32 = nullptr;
+  c->own64 = c->own32 = false;
+  c->sdf_cap64 = c->sdf_cap32 = 0;
+}
+
+int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
+  if (!c->own64 || c->sdf_cap64 < nvox) {
+    if (c->own64 && c->sdf64) (void)hipFree(c->sdf64);
+    c->sdf64 = nullptr; c->own64 = false; c->sdf_cap64 = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->sdf64), nvox * sizeof(double)));
+    c->own64 = true; c->sdf_cap64 = nvox;
+  }
+  if (!c->own32 || c->sdf_cap32 < nvox) {
+    if (c->own32 && c->sdf32) (void)hipFree(c->sdf32);
+    c->sdf32 = nullptr; c->own32 = false; c->sdf_cap32 = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->sdf32), nvox * sizeof(float)));
+    c->own32 = true; c->sdf_cap32 = nvox;
+  }
+  return GTOP_OK;
+}
+
+int auto_waves(const gtop_ctx *c, int m) {
+  int w = c->waves > 0 ? c->waves : (m + 1) / 2;
+  if (w < 1) w = 1;
+  if (w > 8) w = 8;
+  return w;
+}
+
+template <typename R>
+void fill_args(const gtop_ctx *c, GtopKernelArgs<R> &a) {
+  const GtopGrid &g = c->grid;
+  a.nx = g.nx; a.ny = g.ny; a.nz = g.nz;
+  for (int i = 0; i < 3; ++i) {
+    a.origin[i] = (R)g.origin[i];
+    a.min_range[i] = (R)g.min_range[i];
+    a.max_range[i] = (R)g.max_range[i];
+  }
+  a.res = (R)g.res;
+  a.res_inv = (R)g.res_inv;
+  const gtop_params &p = c->prm;
+  a.ws = (R)p.ws; a.wc = (R)p.wc; a.alpha = (R)p.alpha; a.r = (R)p.r; a.d0 = (R)p.d0;
+  a.alpha_v = (R)p.alpha_v; a.r_v = (R)p.r_v; a.v0 = (R)p.v0;
+  a.alpha_a = (R)p.alpha_a; a.r_a = (R)p.r_a; a.a0 = (R)p.a0;
+  a.step = p.step;
+}
+
+template <typename R>
+int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const void *d_Df,
+                const void *d_T, int t_stride, void *d_cost, void *d_grad, hipStream_t stream) {
+  GtopKernelArgs<R> a;
+  fill_args(c, a);
+  a.sdf = sdf;
+  a.x = static_cast<const R *>(d_x);
+  a.Df = static_cast<const R *>(d_Df);
+  a.T = static_cast<const R *>(d_T);
+  a.cost = static_cast<R *>(d_cost);
+  a.grad = static_cast<R *>(d_grad);
+  a.B = B; a.m = m; a.t_stride = t_stride;
+  const int waves = auto_waves(c, m);
+  if (gtop_eval_smem_bytes(m, waves, sizeof(R)) > 160 * 1024)
+    return fail(c, GTOP_ERR_INVALID, "m too large for one workgroup's LDS");
+  HIPCHK(c, gtop_launch_eval<R>(a, waves, c->prm.enable_dyn != 0, 1 << 20, stream));
+  return GTOP_OK;
+}
+
+int check_eval_state(gtop_ctx *c) {
+  if (!c->have_params) return fail(c, GTOP_ERR_STATE, "gtop_set_params has not been called");
+  if (!c->have_grid) return fail(c, GTOP_ERR_STATE, "no distance field set");
+  return GTOP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gtop_abi_version(void) { return GTOP_ABI_VERSION; }
+
+int gtop_create(gtop_ctx **out, int device) {
+  if (!out) return fail(nullptr, GTOP_ERR_INVALID, "gtop_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, GTOP_ERR_NO_DEVICE,
+                std::string("gtop_create: no HIP device (hipGetDeviceCount: ") + hipGetErrorString(e) + ")");
+  if (device < 0 || device >= ndev) return fail(nullptr, GTOP_ERR_INVALID, "gtop_create: device ordinal out of range");
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+    return fail(nullptr, GTOP_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)   // the code objects are gfx950 only
+    return fail(nullptr, GTOP_ERR_NO_DEVICE, std::string("gtop_create: device is ") + prop.gcnArchName + ", need gfx950");
+  if ((e = hipSetDevice(device)) != hipSuccess)
+    return fail(nullptr, GTOP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  gtop_ctx *c = new (std::nothrow) gtop_ctx();
+  if (!c) return fail(nullptr, GTOP_ERR_INVALID, "gtop_create: out of memory");
+  c->device = device;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete c;
+    return fail(nullptr, GTOP_ERR_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return GTOP_OK;
+}
+
+int gtop_destroy(gtop_ctx *c) {
+  if (!c) return GTOP_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  release_sdf(c);
+  void *bufs[] = {c->occ, c->tmp1, c->tmp2, c->zws, c->d_pts, c->vws,
+                  c->d_T, c->d_Df, c->d_x, c->d_cost, c->d_grad};
+  for (void *p : bufs)
+    if (p) (void)hipFree(p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return GTOP_OK;
+}
+
+const char *gtop_last_error(const gtop_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int gtop_set_params(gtop_ctx *c, const gtop_params *p) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!p) return fail(c, GTOP_ERR_INVALID, "params is NULL");
+  if (p->step < 0 || p->step > 2)   // grad_traj_optimizer.cpp:129-131
+    return fail(c, GTOP_ERR_INVALID, "step number error, step should be 0, 1 or 2");
+  if (p->r == 0.0) return fail(c, GTOP_ERR_INVALID, "r must be non-zero");
+  if (p->enable_dyn && (p->r_v == 0.0 || p->r_a == 0.0))
+    return fail(c, GTOP_ERR_INVALID, "r_v and r_a must be non-zero when enable_dyn is set");
+  c->prm = *p;
+  c->have_params = true;
+  return GTOP_OK;
+}
+
+int gtop_set_sdf(gtop_ctx *c, const double *dist_host, int nx, int ny, int nz,
+                 const double origin[3], const double *map_size, double resolution) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!dist_host) return fail(c, GTOP_ERR_INVALID, "dist_host is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = fill_grid(c, nx, ny, nz, origin, map_size, resolution);
+  if (rc) return rc;
+  const size_t nvox = (size_t)nx * ny * nz;
+  if ((rc = own_sdf_buffers(c, nvox))) { c->have_grid = false; return rc; }
+  HIPCHK(c, hipMemcpyAsync(c->sdf64, dist_host, nvox * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
+int gtop_set_sdf_device(gtop_ctx *c, int dtype, const void *dist_dev, int nx, int ny, int nz,
+                        const double origin[3], const double *map_size, double resolution) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!dist_dev) return fail(c, GTOP_ERR_INVALID, "dist_dev is NULL");
+  if (dtype != GTOP_F64 && dtype != GTOP_F32) return fail(c, GTOP_ERR_INVALID, "bad dtype");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = fill_grid(c, nx, ny, nz, origin, map_size, resolution);
+  if (rc) return rc;
+  release_sdf(c);
+  if (dtype == GTOP_F64)
+    c->sdf64 = const_cast<double *>(static_cast<const double *>(dist_dev));
+  else
+    c->sdf32 = const_cast<float *>(static_cast<const float *>(dist_dev));
+  return GTOP_OK;
+}
+
+int gtop_init_sdf_map(gtop_ctx *c, const double map_size[3], const double origin[3], double resolution) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!map_size || !origin || !(resolution > 0.0))
+    return fail(c, GTOP_ERR_INVALID, "initSDFMap: need map_size, origin, resolution > 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  int gs[3];
+  for (int i = 0; i < 3; ++i) gs[i] = (int)std::ceil(map_size[i] / resolution);   // sdf_map.cpp:9
+  int rc = fill_grid(c, gs[0], gs[1], gs[2], origin, map_size, resolution);
+  if (rc) return rc;
+  const size_t nvox = (size_t)gs[0] * gs[1] * gs[2];
+  if ((rc = own_sdf_buffers(c, nvox))) { c->have_grid = false; return rc; }
+  if ((rc = ensure(c, &c->occ, &c->cap_occ, nvox))) return rc;
+  // sdf_map.cpp:22-23: distance 10000, occupancy 0
+  HIPCHK(c, gtop_launch_esdf_reset(c->occ, c->sdf64, nvox, c->stream));
+  HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
+int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (npts < 0 || (npts > 0 && !pts)) return fail(c, GTOP_ERR_INVALID, "bad obstacle list");
+  if (!c->have_grid || !c->own64 || !c->occ)
+    return fail(c, GTOP_ERR_STATE, "updateSDFMap: call gtop_init_sdf_map first");
+  HIPCHK(c, hipSetDevice(c->device));
+  const GtopGrid &g = c->grid;
+  const size_t nvox = (size_t)g.nx * g.ny * g.nz;
+  int rc;
+  if ((rc = ensure(c, &c->tmp1, &c->cap_tmp1, nvox))) return rc;
+  if ((rc = ensure(c, &c->tmp2, &c->cap_tmp2, nvox))) return rc;
+  const size_t ws_lines = gtop_esdf_ws_lines(g);
+  int nmax = g.nx > g.ny ? g.nx : g.ny;
+  nmax = nmax > g.nz ? nmax : g.nz;
+  {
+    const size_t need = ws_lines * (size_t)(nmax + 1);
+    if ((rc = ensure(c, &c->vws, &c->cap_vws, need))) return rc;
+    if ((rc = ensure(c, &c->zws, &c->cap_zws, need))) return rc;
+  }
+  if (npts > 0) {
+    if ((rc = ensure(c, &c->d_pts, &c->pts_cap, (size_t)npts * 3))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, (size_t)npts * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, gtop_launch_esdf_reset(c->occ, c->sdf64, nvox, c->stream));            // resetBuffer
+  HIPCHK(c, gtop_launch_esdf_mark(g, c->d_pts, npts, c->occ, c->stream));         // setOccupancy
+  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->sdf64, c->vws, c->zws, ws_lines,
+                                   c->stream));                                   // updateESDF3d
+  HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
+int gtop_get_sdf(gtop_ctx *c, double *dist_host, int grid_out[3]) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!c->have_grid || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+  HIPCHK(c, hipSetDevice(c->device));
+  const GtopGrid &g = c->grid;
+  if (grid_out) { grid_out[0] = g.nx; grid_out[1] = g.ny; grid_out[2] = g.nz; }
+  if (dist_host) {
+    const size_t nvox = (size_t)g.nx * g.ny * g.nz;
+    HIPCHK(c, hipMemcpyAsync(dist_host, c->sdf64, nvox * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return GTOP_OK;
+}
+
+int gtop_set_problem(gtop_ctx *c, int B, int m, const double *segment_time, int time_stride,
+                     const double *Df) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (B < 1 || m < 2 || !segment_time || !Df || (time_stride != 0 && time_stride != m))
+    return fail(c, GTOP_ERR_INVALID, "set_problem: need B >= 1, m >= 2, time_stride in {0, m}");
+  const size_t nT = time_stride ? (size_t)B * m : (size_t)m;
+  for (size_t i = 0; i < nT; ++i)
+    if (!(segment_time[i] > 0.0)) return fail(c, GTOP_ERR_INVALID, "segment_time must be > 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = 9 * (size_t)(m - 1);
+  int rc;
+  if ((rc = ensure(c, &c->d_T, &c->cap_T, nT))) return rc;
+  if ((rc = ensure(c, &c->d_Df, &c->cap_Df, (size_t)B * 18))) return rc;
+  if ((rc = ensure(c, &c->d_x, &c->cap_x, (size_t)B * n))) return rc;
+  if ((rc = ensure(c, &c->d_grad, &c->cap_grad, (size_t)B * n))) return rc;
+  if ((rc = ensure(c, &c->d_cost, &c->cap_cost, (size_t)B))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_T, segment_time, nT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_Df, Df, (size_t)B * 18 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->B = B; c->m = m; c->t_stride = time_stride;
+  return GTOP_OK;
+}
+
+int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *grad) {
+  if (!c) return GTOP_ERR_INVALID;
+  int rc = check_eval_state(c);
+  if (rc) return rc;
+  if (c->B == 0) return fail(c, GTOP_ERR_STATE, "gtop_set_problem has not been called");
+  if (!c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+  if (B < 1 || B > c->B || !x || !cost || !grad)
+    return fail(c, GTOP_ERR_INVALID, "eval_batch: 1 <= B <= problem batch, non-NULL buffers");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = 9 * (size_t)(c->m - 1);
+  HIPCHK(c, hipMemcpyAsync(c->d_x, x, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_eval<double>(c, c->sdf64, B, c->m, c->d_x, c->d_Df, c->d_T, c->t_stride, c->d_cost,
+                                c->d_grad, c->stream)))
+    return rc;
+  HIPCHK(c, hipMemcpyAsync(cost, c->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
+double gtop_cost_nlopt(unsigned n, const double *x, double *grad, void *vctx) {
+  gtop_ctx *c = static_cast<gtop_ctx *>(vctx);
+  if (!c) return HUGE_VAL;
+  const auto tb1 = std::chrono::steady_clock::now();
+  c->iter_num++;   // grad_traj_optimizer.cpp:284
+  if (c->B == 0 || n != 9u * (unsigned)(c->m - 1) || !x) {
+    fail(c, GTOP_ERR_INVALID, "cost_nlopt: n does not match the problem (9(m-1)) or x is NULL");
+    return HUGE_VAL;
+  }
+  double cost = HUGE_VAL;
+  std::vector<double> gtmp;
+  double *g = grad;
+  if (!g) {   // the reference always computes the gradient (:426)
+    gtmp.resize(n);
+    g = gtmp.data();
+  }
+  if (gtop_eval_batch(c, 1, x, &cost, g) != GTOP_OK) return HUGE_VAL;
+  const auto te1 = std::chrono::steady_clock::now();
+  c->total_time += std::chrono::duration<double>(te1 - tb1).count();   // :436
+  // best-so-far cost curve, :439-447
+  c->vec_time.push_back(std::chrono::duration<double>(te1 - c->time_start).count());
+  if (c->vec_cost.empty() || c->vec_cost.back() > cost)
+    c->vec_cost.push_back(cost);
+  else
+    c->vec_cost.push_back(c->vec_cost.back());
+  return cost;
+}
+
+int gtop_eval_device(gtop_ctx *c, int dtype, int B, int m, const void *d_x, const void *d_Df,
+                     const void *d_T, int time_stride, void *d_cost, void *d_grad, void *hip_stream) {
+  if (!c) return GTOP_ERR_INVALID;
+  int rc = check_eval_state(c);
+  if (rc) return rc;
+  if (B < 0 || m < 2 || (time_stride != 0 && time_stride != m))
+    return fail(c, GTOP_ERR_INVALID, "eval_device: need B >= 0, m >= 2, time_stride in {0, m}");
+  if (B == 0) return GTOP_OK;
+  if (!d_x || !d_Df || !d_T || !d_cost || !d_grad) return fail(c, GTOP_ERR_INVALID, "eval_device: NULL buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  if (dtype == GTOP_F64) {
+    if (!c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+    return launch_eval<double>(c, c->sdf64, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
+  } else if (dtype == GTOP_F32) {
+    if (!c->sdf32) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
+    return launch_eval<float>(c, c->sdf32, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
+  }
+  return fail(c, GTOP_ERR_INVALID, "bad dtype");
+}
+
+int gtop_get_stats(const gtop_ctx *c, int64_t *iter_num, double *total_time) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (iter_num) *iter_num = c->iter_num;
+  if (total_time) *total_time = c->total_time;
+  return GTOP_OK;
+}
+
+int gtop_reset_stats(gtop_ctx *c) {
+  if (!c) return GTOP_ERR_INVALID;
+  c->iter_num = 0;
+  c->total_time = 0.0;
+  return GTOP_OK;
+}
+
+int gtop_get_cost_curve(const gtop_ctx *c, double *cost, double *time, int cap, int *count) {
+  if (!c) return GTOP_ERR_INVALID;
+  const int nn = (int)c->vec_cost.size();
+  if (count) *count = nn;
+  const int k = cap < nn ? cap : nn;
+  for (int i = 0; i < k; ++i) {
+    if (cost) cost[i] = c->vec_cost[i];
+    if (time) time[i] = c->vec_time[i];
+  }
+  return GTOP_OK;
+}
+
+int gtop_clear_cost_curve(gtop_ctx *c) {
+  if (!c) return GTOP_ERR_INVALID;
+  c->vec_cost.clear();   // grad_traj_optimizer.cpp:192-194
+  c->vec_time.clear();
+  c->time_start = std::chrono::steady_clock::now();
+  return GTOP_OK;
+}
+
+int gtop_set_waves_per_block(gtop_ctx *c, int waves) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (waves < 0 || waves > 8) return fail(c, GTOP_ERR_INVALID, "waves per block must be 0 (auto) .. 8");
+  c->waves = waves;
+  return GTOP_OK;
+}
+
+}  // extern "C"

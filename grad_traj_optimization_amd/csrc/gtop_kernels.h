@@ -1,0 +1,60 @@
+// gtop_kernels.h — launch interface between the C-ABI layer (gtop_capi.cpp)
+// and the gfx950 kernels (gtop_kernels.hip, gtop_esdf.hip).  Internal; the
+// public boundary is include/gtop.h.
+#ifndef GTOP_KERNELS_H_
+#define GTOP_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// Kernel arguments of gtop_eval_kernel<R>, all in the arithmetic type R of the
+// launch (double for GTOP_F64, float for GTOP_F32).
+template <typename R>
+struct GtopKernelArgs {
+  // per-trajectory inputs/outputs (HBM)
+  const R *x;    // [B][n]   free variables, axis-major
+  const R *Df;   // [B][3][6]
+  const R *T;    // [B][m] or [m]
+  R *cost;       // [B]
+  R *grad;       // [B][n]
+  int B, m, t_stride;
+  // shared distance field (HBM, z fastest) — SDFMap fields, sdf_map.h:13-23
+  const R *sdf;
+  int nx, ny, nz;
+  R origin[3], min_range[3], max_range[3];
+  R res, res_inv;
+  // parameters — grad_traj_optimizer.cpp:5-32
+  R ws, wc, alpha, r, d0, alpha_v, r_v, v0, alpha_a, r_a, a0;
+  int step;
+};
+
+size_t gtop_eval_smem_bytes(int m, int waves, size_t elem);
+
+template <typename R>
+hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, bool dyn,
+                            int max_blocks, hipStream_t stream);
+
+hipError_t gtop_launch_f64_to_f32(const double *src, float *dst, size_t nelem,
+                                  hipStream_t stream);
+
+// ---- ESDF construction (gtop_esdf.hip) -----------------------------------
+struct GtopGrid {
+  int nx, ny, nz;
+  double origin[3], min_range[3], max_range[3];
+  double res, res_inv;
+};
+
+// occupancy := 0, distance := 10000   (sdf_map.cpp:26-53)
+hipError_t gtop_launch_esdf_reset(uint8_t *occ, double *dist, size_t nvox, hipStream_t stream);
+// setOccupancy per point (sdf_map.cpp:80-99)
+hipError_t gtop_launch_esdf_mark(const GtopGrid &g, const double *pts, int npts, uint8_t *occ,
+                                 hipStream_t stream);
+// updateESDF3d (sdf_map.cpp:310-368): three 1-D lower-envelope sweeps.
+// tmp1/tmp2: nvox doubles each; vws/zws: per-line scratch for `ws_lines` lines.
+size_t gtop_esdf_ws_lines(const GtopGrid &g);
+hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, double *tmp1, double *tmp2,
+                                  double *dist, int *vws, double *zws, size_t ws_lines,
+                                  hipStream_t stream);
+
+#endif  // GTOP_KERNELS_H_

@@ -1,0 +1,385 @@
+// gtop_kernels.hip — hand-written gfx950 (CDNA4) kernels for the batched
+// cost/gradient callback of GTOP.  No MFMA: this is a stencil/gather path.
+//
+// What one launch computes, per trajectory b (reference lines are file:line
+// into EpicOne1/grad_traj_optimization):
+//   cost_b, grad_b = GradTrajOptimizer::getCostAndGradient(x_b)
+//                    (src/grad_traj_optimizer.cpp:281-432)
+// with the distance query SDFMap::getDistWithGradTrilinear
+// (src/sdf_map.cpp:185-242) inlined.
+//
+// Formulation.  The reference multiplies dense L (6m x 3m+3)
+// and R ((3m+3)^2) that it built once from segment_time
+// (src/qp_generator.cpp:357-405).  A is block diagonal, so L's row-block s is
+// A_s^-1 (quintic Hermite, closed form) scattered onto the columns of
+// waypoints s and s+1, and d'Rd = sum_s c_s' Q_s c_s.  The kernel therefore
+// takes (x, Df, T) and works per segment:
+//   phase 1  c_{s,k} = A_s^-1 d_{s,k};  jerk cost and 2 Q_s c (coefficient space)
+//   phase 2  30 samples per segment, one lane per sample (32-lane half-wave
+//            per segment): position/velocity, trilinear SDF gather, exp
+//            penalty; each sample contributes w1_k*[t^j] + w2_k*[j t^(j-1)]
+//            to an 18-entry coefficient-space gradient, reduced through LDS
+//   phase 3  A_s^-T maps the 6 coefficient-space entries of (s,k) to the
+//            derivative space [p0,pT,v0,vT,a0,aT]
+//   phase 4  each free variable sums its two adjacent segments, +1e-5; the
+//            scalar cost is a wavefront shuffle reduction.
+// All structural zeros the reference multiplies through are skipped; nothing
+// else is approximated.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gtop_kernels.h"
+
+namespace {
+
+constexpr int kSamples = 30;     // src/grad_traj_optimizer.cpp:351
+constexpr int kRedVals = 19;     // 18 gradient entries + 1 cost per sample
+constexpr int kRedStride = 65;   // 64 lanes + 1 pad: conflict-free column reads
+
+template <typename R> struct Pair { R x, y; } __attribute__((packed));
+
+template <typename R> __device__ __forceinline__ R gexp(R v);
+template <> __device__ __forceinline__ double gexp<double>(double v) { return exp(v); }
+template <> __device__ __forceinline__ float gexp<float>(float v) { return expf(v); }
+template <typename R> __device__ __forceinline__ R gsqrt(R v);
+template <> __device__ __forceinline__ double gsqrt<double>(double v) { return sqrt(v); }
+template <> __device__ __forceinline__ float gsqrt<float>(float v) { return sqrtf(v); }
+template <typename R> __device__ __forceinline__ R gfloor(R v);
+template <> __device__ __forceinline__ double gfloor<double>(double v) { return floor(v); }
+template <> __device__ __forceinline__ float gfloor<float>(float v) { return floorf(v); }
+template <typename R> __device__ __forceinline__ R gabs(R v);
+template <> __device__ __forceinline__ double gabs<double>(double v) { return fabs(v); }
+template <> __device__ __forceinline__ float gabs<float>(float v) { return fabsf(v); }
+
+// The reference stores pos/vel in `float` locals and widens them again
+// (src/grad_traj_optimizer.cpp:457-465, :477-485).
+__device__ __forceinline__ double round_through_float(double v) { return (double)(float)v; }
+__device__ __forceinline__ float round_through_float(float v) { return v; }
+
+// SDFMap::getDistWithGradTrilinear, src/sdf_map.cpp:185-242.
+// Out of map (src/sdf_map.cpp:55-69, :187): dist = -1; the reference leaves
+// grad uninitialised there, this build defines it as 0.
+template <typename R>
+__device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R pz,
+                                       R &gx, R &gy, R &gz) {
+  const R eps = (R)1e-4;
+  bool out = (px < a.min_range[0] + eps) | (py < a.min_range[1] + eps) |
+             (pz < a.min_range[2] + eps) | (px > a.max_range[0] - eps) |
+             (py > a.max_range[1] - eps) | (pz > a.max_range[2] - eps);
+  if (out) {
+    gx = gy = gz = (R)0;
+    return (R)-1;
+  }
+  const R res = a.res, rinv = a.res_inv;
+  const R half = (R)0.5 * res;
+  // posToIndex(pos - 0.5 res)  (:201-204 -> :71-74)
+  const int ix = (int)gfloor(((px - half) - a.origin[0]) * rinv);
+  const int iy = (int)gfloor(((py - half) - a.origin[1]) * rinv);
+  const int iz = (int)gfloor(((pz - half) - a.origin[2]) * rinv);
+  // indexToPos (:76-78) and diff (:209)
+  const R dx = (px - (((R)ix + (R)0.5) * res + a.origin[0])) * rinv;
+  const R dy = (py - (((R)iy + (R)0.5) * res + a.origin[1])) * rinv;
+  const R dz = (pz - (((R)iz + (R)0.5) * res + a.origin[2])) * rinv;
+
+  // per-axis clamp of the 8 corner indices (:166-174).  z is the fastest
+  // axis, so the two z-corners of each (x,y) column are one 2-element load;
+  // the clamp at the z borders becomes a select on that pair.
+  const int nx = a.nx, ny = a.ny, nz = a.nz;
+  const int x0 = min(max(ix, 0), nx - 1), x1 = min(max(ix + 1, 0), nx - 1);
+  const int y0 = min(max(iy, 0), ny - 1), y1 = min(max(iy + 1, 0), ny - 1);
+  const int zb = min(max(iz, 0), nz - 2);
+  const bool z_lo = iz < 0, z_hi = iz > nz - 2;
+  const R *D = a.sdf;
+  const uint32_t r00 = ((uint32_t)x0 * ny + y0) * nz + zb;
+  const uint32_t r01 = ((uint32_t)x0 * ny + y1) * nz + zb;
+  const uint32_t r10 = ((uint32_t)x1 * ny + y0) * nz + zb;
+  const uint32_t r11 = ((uint32_t)x1 * ny + y1) * nz + zb;
+  const Pair<R> p00 = *reinterpret_cast<const Pair<R> *>(D + r00);
+  const Pair<R> p01 = *reinterpret_cast<const Pair<R> *>(D + r01);
+  const Pair<R> p10 = *reinterpret_cast<const Pair<R> *>(D + r10);
+  const Pair<R> p11 = *reinterpret_cast<const Pair<R> *>(D + r11);
+  // values[x][y][z]
+  const R v000 = z_hi ? p00.y : p00.x, v001 = z_lo ? p00.x : p00.y;
+  const R v010 = z_hi ? p01.y : p01.x, v011 = z_lo ? p01.x : p01.y;
+  const R v100 = z_hi ? p10.y : p10.x, v101 = z_lo ? p10.x : p10.y;
+  const R v110 = z_hi ? p11.y : p11.x, v111 = z_lo ? p11.x : p11.y;
+
+  const R one = (R)1;
+  const R v00 = (one - dx) * v000 + dx * v100;  // :221-224
+  const R v01 = (one - dx) * v001 + dx * v101;
+  const R v10 = (one - dx) * v010 + dx * v110;
+  const R v11 = (one - dx) * v011 + dx * v111;
+  const R v0 = (one - dy) * v00 + dy * v10;     // :226-227
+  const R v1 = (one - dy) * v01 + dy * v11;
+  const R dist = (one - dz) * v0 + dz * v1;     // :229
+  gz = (v1 - v0) * rinv;                        // :231
+  gy = ((one - dz) * (v10 - v00) + dz * (v11 - v01)) * rinv;  // :232-233
+  R g0 = (one - dz) * (one - dy) * (v100 - v000);             // :234-239
+  g0 += (one - dz) * dy * (v110 - v010);
+  g0 += dz * (one - dy) * (v101 - v001);
+  g0 += dz * dy * (v111 - v011);
+  gx = g0 * rinv;
+  return dist;
+}
+
+template <typename R>
+__device__ __forceinline__ R wave_sum(R v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// One workgroup per trajectory (grid-stride over the batch), NW = blockDim/64
+// wavefronts per workgroup, one 32-lane half-wave per polynomial segment.
+template <typename R, bool DYN>
+__global__ void __launch_bounds__(512)
+gtop_eval_kernel(const GtopKernelArgs<R> a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  R *sm = reinterpret_cast<R *>(smem_raw);
+  const int m = a.m, ND = 3 * m + 3, ndp = 3 * m - 3, n = 3 * ndp;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, NW = nthr >> 6;
+  const int half = lane >> 5, li = lane & 31;
+
+  R *dv = sm;              // [3][ND]   d = [Df | dp] per axis (:302-323)
+  R *Ts = dv + 3 * ND;     // [m]       segment_time
+  R *coef = Ts + m;        // [m][3][6] polynomial coefficients (:253-279)
+  R *Gs = coef + 18 * m;   // [m][3][6] coefficient-space gradient
+  R *csm = Gs + 18 * m;    // [m][3]    jerk cost per (segment, axis)
+  R *ccol = csm + 3 * m;   // [m]       wc * collision (+dyn) cost per segment
+  R *gseg = ccol + m;      // [m][3][6] derivative-space gradient per segment
+  R *red = gseg + 18 * m;  // [NW][19][65] per-wave transpose-reduction tile
+  R *myred = red + wave * (kRedVals * kRedStride);
+
+  const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
+  const R wc = a.wc;
+  const bool do_colli = !(gabs(wc) < (R)1e-4);  // :346
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // ---- phase 0: stage this trajectory's x, Df, T in LDS ----
+    {
+      const R *xb = a.x + (size_t)b * n;
+      for (int i = tid; i < n; i += nthr) {
+        const int axis = i / ndp, c = i - axis * ndp;
+        dv[axis * ND + 6 + c] = xb[i];
+      }
+      const R *dfb = a.Df + (size_t)b * 18;
+      for (int i = tid; i < 18; i += nthr) {
+        const int axis = i / 6, j = i - axis * 6;
+        dv[axis * ND + j] = dfb[i];
+      }
+      const R *tb = a.T + (size_t)b * a.t_stride;
+      for (int i = tid; i < m; i += nthr) Ts[i] = tb[i];
+    }
+    __syncthreads();
+
+    // ---- phase 1: per (segment, axis): coefficients, jerk cost, 2Qc ----
+    for (int w = tid; w < 3 * m; w += nthr) {
+      const int s = w / 3, k = w - 3 * s;
+      const R *d = dv + k * ND;
+      // global derivative vector layout (src/qp_generator.cpp:363-387):
+      // [start p,v,a | end p,v,a | waypoint 1 p,v,a | ... | waypoint m-1 p,v,a]
+      const int o0 = (s == 0) ? 0 : 6 + 3 * (s - 1);
+      const int o1 = (s + 1 == m) ? 3 : 6 + 3 * s;
+      const R p0 = d[o0], v0 = d[o0 + 1], a0 = d[o0 + 2];
+      const R pT = d[o1], vT = d[o1 + 1], aT = d[o1 + 2];
+      const R T = Ts[s], T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+      // closed-form A_s^-1 (rows of A_s: src/qp_generator.cpp:185-195)
+      const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
+      const R V = (vT - v0 - a0 * T) * T;
+      const R A = (aT - a0) * T2;
+      const R c0 = p0, c1 = v0, c2 = (R)0.5 * a0;
+      const R c3 = ((R)10 * P - (R)4 * V + (R)0.5 * A) / T3;
+      const R c4 = ((R)-15 * P + (R)7 * V - A) / T4;
+      const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) / T5;
+      R *cf = coef + s * 18 + k * 6;
+      cf[0] = c0; cf[1] = c1; cf[2] = c2; cf[3] = c3; cf[4] = c4; cf[5] = c5;
+      // jerk Hessian Q_s (src/qp_generator.cpp:226-234): i,j in {3,4,5}
+      const R q3 = (R)36 * T * c3 + (R)72 * T2 * c4 + (R)120 * T3 * c5;
+      const R q4 = (R)72 * T2 * c3 + (R)192 * T3 * c4 + (R)360 * T4 * c5;
+      const R q5 = (R)120 * T3 * c3 + (R)360 * T4 * c4 + (R)720 * T5 * c5;
+      csm[w] = c3 * q3 + c4 * q4 + c5 * q5;   // c'Qc  == this (s,k)'s share of d'Rd (:326-327)
+      R *g = Gs + s * 18 + k * 6;             // ws * 2Qc == share of ws*(2Rfp'df + 2Rpp dp) (:330-336)
+      g[0] = (R)0; g[1] = (R)0; g[2] = (R)0;
+      g[3] = ws * (R)2 * q3; g[4] = ws * (R)2 * q4; g[5] = ws * (R)2 * q5;
+      if (k == 0) ccol[s] = (R)0;
+    }
+    __syncthreads();
+
+    // ---- phase 2: collision samples (:345-409) ----
+    if (do_colli) {
+      for (int s0 = 0; s0 < m; s0 += 2 * NW) {   // block-uniform trip count
+        const int s = s0 + wave * 2 + half;
+        R acc[kRedVals];
+#pragma unroll
+        for (int v = 0; v < kRedVals; ++v) acc[v] = (R)0;
+        if (s < m && li < kSamples) {
+          const R Tseg = Ts[s];
+          const R dt = Tseg / (R)30.0;             // :351
+          R t = (R)1e-3;                           // :353: t accumulates by repeated addition
+          for (int i = 0; i < li; ++i) t += dt;
+          if (t < Tseg) {
+            const R *cf = coef + s * 18;
+            const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+            R pos[3], vel[3], acc3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const R *q = cf + 6 * k;
+              // :457-465 / :477-485, same left-to-right sums, then the float round trip
+              pos[k] = round_through_float(q[0] + q[1] * t + q[2] * t2 + q[3] * t3 + q[4] * t4 + q[5] * t5);
+              vel[k] = round_through_float(q[1] + (R)2 * q[2] * t + (R)3 * q[3] * t2 + (R)4 * q[4] * t3 + (R)5 * q[5] * t4);
+              if (DYN)  // :497-502
+                acc3[k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
+            }
+            const R vn = gsqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;  // :358
+            R g3[3];
+            const R dist = sdf_query(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2]);  // :363
+            const R e = gexp(-(dist - a.d0) / a.r);
+            const R cd = a.alpha * e;              // :509
+            const R gd = -(a.alpha / a.r) * e;     // :514
+            R csum = wc * (cd * vn * dt);          // :373, weighted as in :417-418
+            // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
+            R w1[3], w2[3], w3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              w1[k] = wc * (gd * g3[k] * cd * vn) * dt;
+              w2[k] = wc * (cd * (vel[k] / vn)) * dt;
+              w3[k] = (R)0;
+            }
+            if (DYN && a.step == 2) {
+              // the block commented out at :383-407, formulas :517-535.  cv/ca
+              // in the gradient are the values left by the LAST axis of the
+              // cost loop, and there is no sign(v) factor — both as written.
+              R cv = (R)0, ca = (R)0;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                cv = a.alpha_v * gexp((gabs(vel[k]) - a.v0) / a.r_v);
+                ca = a.alpha_a * gexp((gabs(acc3[k]) - a.a0) / a.r_a);
+                csum += (cv + ca) * vn * dt;       // wv = wa = 1 (:412)
+              }
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                const R gv = (a.alpha_v / a.r_v) * gexp((gabs(vel[k]) - a.v0) / a.r_v);
+                const R ga = (a.alpha_a / a.r_a) * gexp((gabs(acc3[k]) - a.a0) / a.r_a);
+                w2[k] += (gv * vn + cv * (vel[k] / vn) + ca * (vel[k] / vn)) * dt;
+                w3[k] = (ga * vn) * dt;            // on T*V*V
+              }
+            }
+            // T = [1,t,..,t^5] (:544-551); T*V = [0,1,2t,3t^2,4t^3,5t^4]; T*V*V = [0,0,2,6t,12t^2,20t^3]
+            const R tv[6] = {(R)1, t, t2, t3, t4, t5};
+            const R td[6] = {(R)0, (R)1, (R)2 * t, (R)3 * t2, (R)4 * t3, (R)5 * t4};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+              for (int j = 0; j < 6; ++j) acc[k * 6 + j] = w1[k] * tv[j] + w2[k] * td[j];
+              if (DYN) {
+                acc[k * 6 + 2] += w3[k] * (R)2;
+                acc[k * 6 + 3] += w3[k] * (R)6 * t;
+                acc[k * 6 + 4] += w3[k] * (R)12 * t2;
+                acc[k * 6 + 5] += w3[k] * (R)20 * t3;
+              }
+            }
+            acc[18] = csum;
+          }
+        }
+        // transpose-reduce over the 30 samples of each half-wave through LDS
+#pragma unroll
+        for (int v = 0; v < kRedVals; ++v) myred[v * kRedStride + lane] = acc[v];
+        __syncthreads();
+        if (s < m && li < kRedVals) {
+          const R *col = myred + li * kRedStride + half * 32;
+          R sum = (R)0;
+#pragma unroll
+          for (int i = 0; i < kSamples; ++i) sum += col[i];
+          if (li < 18) Gs[s * 18 + li] += sum;
+          else ccol[s] = sum;
+        }
+        __syncthreads();
+      }
+    }
+
+    // ---- phase 3: coefficient space -> derivative space (A_s^-T) ----
+    for (int w = tid; w < 3 * m; w += nthr) {
+      const int s = w / 3;
+      const R *g = Gs + w * 6;
+      const R T = Ts[s], T2 = T * T, T3 = T2 * T;
+      const R H3 = g[3] / T3, H4 = g[4] / (T3 * T), H5 = g[5] / (T3 * T2);
+      const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
+      R *o = gseg + w * 6;   // [p0, pT, v0, vT, a0, aT]
+      o[0] = g[0] - ap;
+      o[1] = ap;
+      o[2] = g[1] + T * ((R)-6 * H3 + (R)8 * H4 - (R)3 * H5);
+      o[3] = T * ((R)-4 * H3 + (R)7 * H4 - (R)3 * H5);
+      o[4] = (R)0.5 * g[2] + T2 * ((R)-1.5 * H3 + (R)1.5 * H4 - (R)0.5 * H5);
+      o[5] = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
+    }
+    __syncthreads();
+
+    // ---- phase 4: gather to the free variables, +1e-5 (:425-432); cost (:417-418) ----
+    {
+      R *gb = a.grad + (size_t)b * n;
+      for (int i = tid; i < n; i += nthr) {
+        const int axis = i / ndp, c = i - axis * ndp;
+        const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
+        const R v = gseg[((wpt - 1) * 3 + axis) * 6 + 2 * der + 1] +   // end of segment wpt-1
+                    gseg[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
+        gb[i] = v + (R)1e-5;
+      }
+      if (wave == 0) {
+        R part = (R)0;
+        for (int i = lane; i < 3 * m; i += 64) part += ws * csm[i];
+        for (int i = lane; i < m; i += 64) part += ccol[i];
+        part = wave_sum(part);
+        if (lane == 0) a.cost[b] = part + (R)1e-3;
+      }
+    }
+    __syncthreads();   // LDS is reused by the next trajectory of this block
+  }
+}
+
+}  // namespace
+
+size_t gtop_eval_smem_bytes(int m, int waves, size_t elem) {
+  const size_t ND = 3 * (size_t)m + 3;
+  size_t elems = 3 * ND + m + 18 * (size_t)m * 3 + 3 * (size_t)m + m +
+                 (size_t)waves * kRedVals * kRedStride;
+  return elems * elem;
+}
+
+template <typename R>
+hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, bool dyn,
+                            int max_blocks, hipStream_t stream) {
+  if (args.B <= 0) return hipSuccess;
+  const size_t smem = gtop_eval_smem_bytes(args.m, waves, sizeof(R));
+  auto kern = dyn ? gtop_eval_kernel<R, true> : gtop_eval_kernel<R, false>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  int grid = args.B < max_blocks ? args.B : max_blocks;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), smem, stream, args);
+  return hipGetLastError();
+}
+
+template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, bool, int, hipStream_t);
+template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, bool, int, hipStream_t);
+
+// ---------------------------------------------------------------------------
+// fp64 -> fp32 copy of the distance field for the GTOP_F32 path
+// ---------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256)
+gtop_f64_to_f32_kernel(const double *__restrict__ src, float *__restrict__ dst, size_t nelem) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nelem; i += stride) dst[i] = (float)src[i];
+}
+}  // namespace
+
+hipError_t gtop_launch_f64_to_f32(const double *src, float *dst, size_t nelem, hipStream_t stream) {
+  if (nelem == 0) return hipSuccess;
+  hipLaunchKernelGGL(gtop_f64_to_f32_kernel, dim3(2048), dim3(256), 0, stream, src, dst, nelem);
+  return hipGetLastError();
+}

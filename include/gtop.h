@@ -1,0 +1,166 @@
+/*
+ * gtop.h — C-ABI of the MI355X-native batched cost/gradient path of GTOP.
+ *
+ * This is the drop-in boundary.  Each entry point names the
+ * reference interface it replaces as file:line into the reference tree
+ * (EpicOne1/grad_traj_optimization).  Plain pointers and sizes only; no C++
+ * or torch types; no exceptions cross this boundary — every function returns
+ * a gtop_status (0 = OK) except gtop_cost_nlopt, whose shape is fixed by
+ * NLopt's `nlopt_func`.
+ *
+ * Conventions
+ *   m        number of polynomial segments (= #waypoints - 1), m >= 2
+ *   n        free variables per trajectory = 9 (m - 1)
+ *   x, grad  n values per trajectory, axis-major: x[i + axis*(3m-3)]
+ *            (src/grad_traj_optimizer.cpp:182-187, :428-432)
+ *   Df       3 x 6 per trajectory, row-major: per axis
+ *            [p_start, v_start, a_start, p_end, v_end, a_end]
+ *            (src/qp_generator.cpp:407-431)
+ *   T        segment times, m per trajectory (src/grad_traj_optimizer.cpp:73-81)
+ *   dist     voxel distance field, index x*ny*nz + y*nz + z
+ *            (src/sdf_map.cpp:172-173)
+ *
+ * One gtop_ctx per host thread / HIP stream; a context is not thread-safe
+ * (neither is the reference object it replaces: it mutates iter_num,
+ * total_time and the cost curve on every call,
+ * src/grad_traj_optimizer.cpp:284,436,439-447).
+ */
+#ifndef GTOP_H_
+#define GTOP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gtop_ctx gtop_ctx;
+
+typedef enum {
+  GTOP_OK = 0,
+  GTOP_ERR_INVALID = 1,   /* bad argument (NULL, m < 2, size mismatch ...) */
+  GTOP_ERR_HIP = 2,       /* a HIP runtime call failed; see gtop_last_error */
+  GTOP_ERR_NO_DEVICE = 3, /* no gfx950 device visible */
+  GTOP_ERR_STATE = 4      /* call order: SDF / problem / params not set */
+} gtop_status;
+
+typedef enum { GTOP_F64 = 0, GTOP_F32 = 1 } gtop_dtype;
+
+/* The ROS parameters the callback reads (ctor,
+ * src/grad_traj_optimizer.cpp:5-32) plus `step` (:132, :413-415).
+ * enable_dyn switches on the velocity/acceleration penalty block that is
+ * commented out in the reference (:383-407); 0 = behave as shipped. */
+typedef struct {
+  double ws, wc;           /* w_smooth, w_collision  */
+  double alpha, r, d0;     /* distance penalty       */
+  double alpha_v, r_v, v0; /* velocity penalty       */
+  double alpha_a, r_a, a0; /* acceleration penalty   */
+  int32_t step;            /* OPT_INITIAL_TRY 0 / OPT_FIRST_STEP 1 / OPT_SECOND_STEP 2 */
+  int32_t enable_dyn;
+} gtop_params;
+
+/* ---- lifetime ------------------------------------------------------- */
+
+/* Replaces GradTrajOptimizer::GradTrajOptimizer()
+ * (src/grad_traj_optimizer.cpp:3-33).  `device` is the HIP device ordinal.
+ * Fails with GTOP_ERR_NO_DEVICE when no GPU is present: there is no CPU
+ * fallback behind this ABI. */
+int gtop_create(gtop_ctx **out, int device);
+int gtop_destroy(gtop_ctx *ctx);
+/* Text of the last error on this context ("" if none); with ctx == NULL,
+ * the text of the calling thread's last failed gtop_create. */
+const char *gtop_last_error(const gtop_ctx *ctx);
+/* Library/ABI version, for the loader to check. */
+int gtop_abi_version(void);
+
+/* ---- configuration -------------------------------------------------- */
+
+/* Replaces the 21 ros::param::get calls of the ctor
+ * (src/grad_traj_optimizer.cpp:5-32) and `this->step = step` (:132). */
+int gtop_set_params(gtop_ctx *ctx, const gtop_params *p);
+
+/* Replaces GradTrajOptimizer::initSDFMap + the distance_buffer that
+ * updateSDFMap leaves behind (src/grad_traj_optimizer.cpp:112-126,
+ * src/sdf_map.cpp:3-24).  `dist_host` holds nx*ny*nz doubles; it is uploaded
+ * to HBM (an fp32 copy is made on the device for the GTOP_F32 path).
+ * `map_size` may be NULL (then max_range = origin + grid*res); when given,
+ * max_range = origin + map_size as src/sdf_map.cpp:12 has it.
+ * Requires nx, ny, nz >= 2 and nx*ny*nz < 2^31. */
+int gtop_set_sdf(gtop_ctx *ctx, const double *dist_host, int nx, int ny, int nz,
+                 const double origin[3], const double *map_size,
+                 double resolution);
+
+/* Same, from a distance field already resident in HBM (dtype says which).
+ * The buffer is borrowed, not copied; it must outlive its use. */
+int gtop_set_sdf_device(gtop_ctx *ctx, int dtype, const void *dist_dev, int nx,
+                        int ny, int nz, const double origin[3],
+                        const double *map_size, double resolution);
+
+/* Replaces GradTrajOptimizer::updateSDFMap (src/grad_traj_optimizer.cpp:117-126
+ * -> src/sdf_map.cpp:26-53, :80-99, :310-368): reset, mark the voxel under
+ * each of the `npts` obstacle points (xyz triples), rebuild the Euclidean
+ * distance field on the device and keep it resident.  Call after an SDF
+ * geometry has been set with gtop_init_sdf_map. */
+int gtop_init_sdf_map(gtop_ctx *ctx, const double map_size[3],
+                      const double origin[3], double resolution);
+int gtop_update_sdf_map(gtop_ctx *ctx, const double *obstacle_pts, int npts);
+/* Copy the resident fp64 distance field back to the host (nx*ny*nz doubles). */
+int gtop_get_sdf(gtop_ctx *ctx, double *dist_host, int grid_out[3]);
+
+/* Replaces the problem state setPath/setKinoPath leave in the object
+ * (segment_time, Df; L and R follow from segment_time and are formed on the
+ * device: src/grad_traj_optimizer.cpp:67-110, src/qp_generator.cpp:357-405).
+ * B trajectories of m segments each; time_stride = m (per-trajectory times)
+ * or 0 (one shared time vector).  Host pointers; uploaded to HBM. */
+int gtop_set_problem(gtop_ctx *ctx, int B, int m, const double *segment_time,
+                     int time_stride, const double *Df);
+
+/* ---- evaluation ----------------------------------------------------- */
+
+/* Batched form of GradTrajOptimizer::costFunc / getCostAndGradient
+ * (src/grad_traj_optimizer.cpp:554-562, :281-448) for the problem set by
+ * gtop_set_problem: x, grad are B*n host doubles, cost B host doubles.
+ * fp64 on the device; includes the PCIe copies. */
+int gtop_eval_batch(gtop_ctx *ctx, int B, const double *x, double *cost,
+                    double *grad);
+
+/* Exactly NLopt's `nlopt_func` (what nlopt::opt::set_min_objective's
+ * trampoline calls; src/grad_traj_optimizer.cpp:140, :554-562): evaluates
+ * trajectory 0 of the current problem.  `grad` may be NULL (the reference
+ * always fills it, :426; NLopt passes NULL to derivative-free algorithms).
+ * Returns the cost; on error returns HUGE_VAL and records gtop_last_error.
+ * Also keeps iter_num / total_time / the best-so-far cost curve
+ * (:284, :436, :439-447) — read them with gtop_get_stats/gtop_get_cost_curve. */
+double gtop_cost_nlopt(unsigned n, const double *x, double *grad, void *ctx);
+
+/* Device-resident form: every pointer is a HIP device pointer of `dtype`
+ * elements; launches on `hip_stream` (a hipStream_t, NULL = default stream)
+ * and returns without synchronising.  Does not touch the problem set by
+ * gtop_set_problem.  d_T: B*m (time_stride = m) or m (time_stride = 0). */
+int gtop_eval_device(gtop_ctx *ctx, int dtype, int B, int m, const void *d_x,
+                     const void *d_Df, const void *d_T, int time_stride,
+                     void *d_cost, void *d_grad, void *hip_stream);
+
+/* ---- bookkeeping the reference keeps inside the callback ------------ */
+
+/* iter_num and total_time (src/grad_traj_optimizer.cpp:284, :436); reset as
+ * optimizeTrajectory does after a step-2 solve (:236-239). */
+int gtop_get_stats(const gtop_ctx *ctx, int64_t *iter_num, double *total_time);
+int gtop_reset_stats(gtop_ctx *ctx);
+/* Best-so-far cost curve (src/grad_traj_optimizer.cpp:439-447,
+ * include/grad_traj_optimization/grad_traj_optimizer.h:127-130).  Copies up
+ * to `cap` entries; *count receives the number available. */
+int gtop_get_cost_curve(const gtop_ctx *ctx, double *cost, double *time,
+                        int cap, int *count);
+int gtop_clear_cost_curve(gtop_ctx *ctx);
+
+/* ---- tuning knobs (not in the reference) ---------------------------- */
+
+/* waves per trajectory block (0 = auto: ceil(m/2) capped at 8). */
+int gtop_set_waves_per_block(gtop_ctx *ctx, int waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTOP_H_ */

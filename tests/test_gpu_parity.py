@@ -1,0 +1,48 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle on the same
+seeded inputs.  Tolerance: 1e-5 relative in fp64 (BASELINE.json north_star);
+the fp32 path's looser bound is stated where it is tested."""
+import numpy as np
+import pytest
+
+from grad_traj_optimization_amd import problem
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-5
+
+
+def rel_err(c, g, c_ref, g_ref):
+    rc = np.max(np.abs(c - c_ref) / np.abs(c_ref))
+    rg = np.max(np.max(np.abs(g - g_ref), axis=1) / np.max(np.abs(g_ref), axis=1))
+    return rc, rg
+
+
+@pytest.fixture(scope="module")
+def scene(gtop, oracle_mod):
+    mp = problem.make_map((60, 50, 30), density=0.03, seed=11)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    sdf = oracle_mod.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+    assert sdf.grid == tuple(mp.grid) == tuple(ctx.grid)
+    sdf.build_from_occupancy(mp.occupancy)
+    return mp, ctx, sdf
+
+
+def test_esdf_bit_exact(scene):
+    mp, ctx, sdf = scene
+    d = ctx.get_sdf().reshape(-1)
+    assert np.array_equal(d, sdf.dist)
+
+
+@pytest.mark.parametrize("m", [2, 3, 6, 7, 10, 12, 17])
+@pytest.mark.parametrize("kw", [dict(), dict(step=1), dict(wc=0.0), dict(ws=0.0), dict(ws=20.0, wc=1.0)])
+def test_fp64_parity_host_api(scene, oracle_mod, m, kw):
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(24, m, mp, seed=100 + m)
+    ctx.set_params(**kw)
+    ctx.set_problem(b.T, b.Df)
+    c, g = ctx.eval_batch(b.x)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params(**kw))
+    rc, rg = rel_err(c, g, c_ref, g_ref)
+    assert rc <= TOL64 and rg <= TOL64, (rc, rg)
