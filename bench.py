@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""bench.py — cost+gradient evaluations per second of the batched GTOP callback.
+
+One "step" = one pass of the hot path (GradTrajOptimizer::getCostAndGradient,
+src/grad_traj_optimizer.cpp:281-448 of the reference) over one resident batch
+of synthetic trajectories.  Default workload = BASELINE.json configs[1]:
+1 024 trajectories per GPU, 20 control points (m = 6 segments, 45 free
+variables), shared 200^3 distance field, fp64.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the batch shards across ranks (weak scaling: per-GPU batch fixed),
+the distance field is replicated, and the only collective is a bucketed RCCL
+all-gather of the per-trajectory costs (one collective per bucket of steps,
+overlapped with the next bucket's kernels).
+
+Rank 0 prints ONE JSON line (contract in the task statement), extended with
+`roofline` (dominant kernel: gtop_eval_kernel, HBM-bound, algorithmic bytes
+of SURVEY.md §8d) and `cpu_baseline` (the oracle's C restatement timed on this
+box's host cores; N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(m, elem):
+    """per evaluation, e*[(9(m-1)+18+m) + (1+9(m-1))] + e*8*30*m."""
+    n = 9 * (m - 1)
+    return elem * ((n + 18 + m) + (1 + n)) + elem * 8 * 30 * m
+
+
+def host_threads():
+    """Threads the CPU legs may use: the affinity mask, capped by the cgroup CPU
+    quota and by 16 (a 1-GPU box's CPU share) — os.cpu_count() reports the
+    whole host and would oversubscribe the quota with spinning OpenMP threads."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=1024, help="trajectories PER GPU")
+    ap.add_argument("--segments", type=int, default=6, help="m (6 -> '20 control points')")
+    ap.add_argument("--grid", type=int, default=200, help="distance field is grid^3")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--density", type=float, default=0.02)
+    ap.add_argument("--bucket", type=int, default=50, help="steps per graph / per cost all-gather")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--waves", type=int, default=0, help="waves per trajectory block (0 = auto)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import grad_traj_optimization_amd as gtop
+    from grad_traj_optimization_amd import problem
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    tdtype = torch.float64 if args.dtype == "f64" else torch.float32
+    elem = 8 if args.dtype == "f64" else 4
+    m, Bl = args.segments, args.batch
+    B_total = Bl * world
+
+    # ---- synthetic inputs (same seeds on every rank; each rank keeps its shard) ----
+    mp = problem.make_map(args.grid, density=args.density, seed=0)
+    ctx = gtop.GtopContext(device=local_rank)
+    if args.waves:
+        ctx.set_waves_per_block(args.waves)
+    t0 = time.time()
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())       # ESDF built on the GPU, stays resident
+    esdf_s = time.time() - t0
+    if rank == 0:
+        log(f"map {args.grid}^3 built on GPU in {esdf_s:.3f} s")
+    batch = problem.make_trajectories(B_total, m, mp, seed=1)
+    lo, hi = problem.shard_range(B_total, rank, world)
+    x = torch.tensor(batch.x[lo:hi], dtype=tdtype, device=dev)
+    Df = torch.tensor(batch.Df[lo:hi].reshape(-1, 18), dtype=tdtype, device=dev)
+    T = torch.tensor(batch.T[lo:hi], dtype=tdtype, device=dev)
+    n = x.shape[1]
+
+    G = max(1, min(args.bucket, args.steps))
+    while args.steps % G:
+        G -= 1
+    nbuckets = args.steps // G
+    cost_ring = [torch.zeros(G, hi - lo, dtype=tdtype, device=dev) for _ in range(2)]
+    grad = torch.zeros(hi - lo, n, dtype=tdtype, device=dev)
+    gathered = [torch.zeros(world, G, hi - lo, dtype=tdtype, device=dev) for _ in range(2)] if world > 1 else None
+
+    # ---- parity gate (rank 0): HIP vs oracle on a subsample of this rank's shard ----
+    parity = None
+    if rank == 0:
+        from oracle import oracle
+        nchk = min(256, hi - lo)
+        c_dev, g_dev = ctx.eval_device(x[:nchk].contiguous(), Df[:nchk].contiguous(), T[:nchk].contiguous())
+        torch.cuda.synchronize()
+        dist_host = ctx.get_sdf()
+        osdf = oracle.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+        osdf.dist[:] = dist_host.reshape(-1)
+        c_ref, g_ref, _ = oracle.eval_batch(batch.T[lo:lo + nchk], batch.Df[lo:lo + nchk], batch.x[lo:lo + nchk],
+                                            osdf, oracle.make_params(), nthreads=host_threads())
+        c = c_dev.double().cpu().numpy()
+        gg = g_dev.double().cpu().numpy()
+        rc = float(np.max(np.abs(c - c_ref) / np.abs(c_ref)))
+        rg = float(np.max(np.max(np.abs(gg - g_ref), axis=1) / np.max(np.abs(g_ref), axis=1)))
+        tol = 1e-5 if args.dtype == "f64" else 5e-2
+        parity = {"n": nchk, "max_rel_cost": rc, "max_rel_grad": rg, "tol": tol, "ok": bool(rc <= tol and rg <= tol)}
+        log(f"parity {parity}")
+        if not parity["ok"]:
+            print(f"bench.py: PARITY FAILED {parity}", file=sys.stderr)
+            sys.exit(3)
+
+    # ---- launch plan: one hipGraph per cost ring buffer, G steps each ----
+    stream = torch.cuda.current_stream(dev)
+    graphs = None
+    launch_mode = "eager"
+    if not args.no_graph:
+        try:
+            graphs = []
+            for j in range(2):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    for s in range(G):
+                        ctx.eval_device(x, Df, T, cost_ring[j][s], grad)
+                graphs.append(gph)
+            launch_mode = "hipgraph"
+        except Exception as e:   # capture unsupported: fall back to eager launches, say so
+            print(f"bench.py: graph capture failed ({e}); using eager launches", file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
+
+    if rank == 0:
+        log(f"launch mode {launch_mode}, {G} steps per bucket")
+    pending = [None, None]
+
+    def run_bucket(b):
+        j = b & 1
+        if pending[j] is not None:      # ring j is about to be overwritten: its all-gather must be done
+            pending[j].wait()
+            pending[j] = None
+        if graphs is not None:
+            graphs[j].replay()
+        else:
+            for s in range(G):
+                ctx.eval_device(x, Df, T, cost_ring[j][s], grad)
+        if world > 1:
+            pending[j] = dist.all_gather_into_tensor(gathered[j], cost_ring[j], async_op=True)
+
+    def drain():
+        for j in range(2):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warmup ----
+    wb = max(1, math.ceil(args.warmup / G)) if args.warmup > 0 else 0
+    for b in range(wb):
+        run_bucket(b)
+    drain()
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K = nbuckets*G steps ----
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for b in range(nbuckets):
+        run_bucket(b)
+    ev1.record(stream)
+    drain()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps     # avg per launch on the launch stream (HIP events)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        # every rank must now hold every rank's costs of the last bucket
+        last = gathered[(nbuckets - 1) & 1]
+        assert torch.equal(last[rank], cost_ring[(nbuckets - 1) & 1])
+
+    if rank == 0:
+        log(f"timed region done: {elapsed:.4f} s for {args.steps} steps")
+        evals = B_total * args.steps
+        value = evals / elapsed
+        bpe = algorithmic_bytes(m, elem)
+        achieved = (hi - lo) * bpe / (kern_ms * 1e-3) / 1e9    # GB/s, per launch on this rank
+        out = {
+            "metric": "cost+grad evals/sec (batched trajectories)",
+            "value": value, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": wb * G,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": f"B={Bl}/GPU x {m} segments ({3 * m + 3} ctrl pts, n={n}), {args.grid}^3 SDF, {args.dtype}"
+                            + (" [BASELINE.json configs[1]]" if (Bl, m, args.grid, args.dtype) == (1024, 6, 200, "f64") else ""),
+                "batch_per_gpu": Bl, "global_batch": B_total, "segments": m, "free_vars": n,
+                "sdf_grid": [args.grid] * 3, "sdf_occupied_frac": float(mp.occupancy.mean()),
+                "params": "opti_node.launch (ws=1, wc=5, alpha=10, d0=0.8, r=0.5), step=2",
+                "parallelism": f"batch-sharded x{world}, SDF replicated, bucketed RCCL all-gather of costs"
+                               if world > 1 else "single GPU",
+                "launch": launch_mode, "steps_per_bucket": G,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "gtop_eval_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_eval": bpe, "evals_per_launch": hi - lo,
+                "avg_launch_us": kern_ms * 1e3,
+            },
+            "parity": parity,
+            "esdf_build_s": esdf_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, batch, mp, ctx)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, batch, mp, ctx):
+    """The oracle's C restatement (kind = "port": the reference itself cannot be
+    built here) on a bounded sample of the SAME workload: single thread, as the
+    reference's NLopt callback runs; an all-cores figure is added beside it."""
+    from oracle import oracle
+    osdf = oracle.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+    osdf.dist[:] = ctx.get_sdf().reshape(-1)
+    prm = oracle.make_params()
+    ns = min(256, batch.x.shape[0])
+    Ts, Dfs, xs = batch.T[:ns], batch.Df[:ns], batch.x[:ns]
+    _, _, sec = oracle.eval_batch(Ts, Dfs, xs, osdf, prm, reps=1, nthreads=1)      # calibrate
+    reps = max(1, int(args.cpu_seconds * 0.6 / max(sec, 1e-6)))
+    _, _, sec1 = oracle.eval_batch(Ts, Dfs, xs, osdf, prm, reps=reps, nthreads=1)
+    ncore = host_threads()
+    reps_all = max(1, int(args.cpu_seconds * 0.3 * ncore / max(sec, 1e-6)))
+    _, _, secn = oracle.eval_batch(Ts, Dfs, xs, osdf, prm, reps=reps_all, nthreads=ncore)
+    return {
+        "value": ns * reps / sec1, "unit": "evals/s", "cores": 1, "kind": "port",
+        "sample": f"{ns} trajectories of the same batch x {reps} passes, callback only (L/R setup untimed), "
+                  f"{sec1:.1f} s",
+        "all_cores": {"value": ns * reps_all / secn, "cores": ncore, "seconds": secn},
+    }
+
+
+if __name__ == "__main__":
+    main()
