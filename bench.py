@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--waves", type=int, default=0, help="waves per trajectory block (0 = auto)")
+    ap.add_argument("--spl", type=int, default=0, help="samples per lane (0 = auto)")
     return ap.parse_args()
 
 
@@ -115,8 +116,8 @@ def main():
     # ---- synthetic inputs (same seeds on every rank; each rank keeps its shard) ----
     mp = problem.make_map(args.grid, density=args.density, seed=0)
     ctx = gtop.GtopContext(device=local_rank)
-    if args.waves:
-        ctx.set_waves_per_block(args.waves)
+    if args.waves or args.spl:
+        ctx.set_launch_geometry(args.waves, args.spl)
     t0 = time.time()
     ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
     ctx.update_sdf_map(mp.obstacle_points())       # ESDF built on the GPU, stays resident

@@ -94,7 +94,7 @@ def load_library():
         "gtop_reset_stats": (C.c_int, [vp]),
         "gtop_get_cost_curve": (C.c_int, [vp, dp, dp, C.c_int, ip]),
         "gtop_clear_cost_curve": (C.c_int, [vp]),
-        "gtop_set_waves_per_block": (C.c_int, [vp, C.c_int]),
+        "gtop_set_launch_geometry": (C.c_int, [vp, C.c_int, C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -198,8 +198,8 @@ class GtopContext:
         self._chk(self._L.gtop_set_problem(self._h, B, m, _p(T), stride, _p(Df)))
         self.B, self.m = B, m
 
-    def set_waves_per_block(self, waves):
-        self._chk(self._L.gtop_set_waves_per_block(self._h, int(waves)))
+    def set_launch_geometry(self, waves=0, samples_per_lane=0):
+        self._chk(self._L.gtop_set_launch_geometry(self._h, int(waves), int(samples_per_lane)))
 
     # -- evaluation --
     def eval_batch(self, x):

@@ -44,6 +44,7 @@ struct gtop_ctx {
   size_t cap_T = 0, cap_Df = 0, cap_x = 0, cap_grad = 0, cap_cost = 0;
 
   int waves = 0;   // 0 = auto
+  int spl = 0;     // samples per lane, 0 = auto
 
   // bookkeeping of the callback (grad_traj_optimizer.cpp:284, :436, :439-447)
   int64_t iter_num = 0;
@@ -126,11 +127,20 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
   return GTOP_OK;
 }
 
-int auto_waves(const gtop_ctx *c, int m) {
-  int w = c->waves > 0 ? c->waves : (m + 1) / 2;
+// Launch geometry.  spl (samples per lane) sets how many segments one
+// wavefront holds (2, 4, 6, 10, 12 for spl 1, 2, 3, 5, 6).  Auto: large
+// batches are throughput-bound -> fewest wavefronts per trajectory (spl 3,
+// or 6 when m > 6); small batches are latency-bound -> spread a trajectory
+// over more wavefronts (spl 1).
+void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl) {
+  int s = c->spl;
+  if (s == 0) s = (B >= 4096) ? (m > 6 ? 6 : 3) : 1;
+  const int spw = gtop_eval_segments_per_wave(s);
+  int w = c->waves > 0 ? c->waves : (m + spw - 1) / spw;
   if (w < 1) w = 1;
   if (w > 8) w = 8;
-  return w;
+  *waves = w;
+  *spl = s;
 }
 
 template <typename R>
@@ -139,13 +149,15 @@ void fill_args(const gtop_ctx *c, GtopKernelArgs<R> &a) {
   a.nx = g.nx; a.ny = g.ny; a.nz = g.nz;
   for (int i = 0; i < 3; ++i) {
     a.origin[i] = (R)g.origin[i];
-    a.min_range[i] = (R)g.min_range[i];
-    a.max_range[i] = (R)g.max_range[i];
+    a.lo[i] = (R)g.min_range[i] + (R)1e-4;   // sdf_map.cpp:56-57
+    a.hi[i] = (R)g.max_range[i] - (R)1e-4;   // sdf_map.cpp:62-63
   }
   a.res = (R)g.res;
   a.res_inv = (R)g.res_inv;
   const gtop_params &p = c->prm;
-  a.ws = (R)p.ws; a.wc = (R)p.wc; a.alpha = (R)p.alpha; a.r = (R)p.r; a.d0 = (R)p.d0;
+  a.ws = (R)p.ws; a.wc = (R)p.wc; a.alpha = (R)p.alpha; a.d0 = (R)p.d0;
+  a.inv_r = (R)1 / (R)p.r;
+  a.alpha_over_r = (R)p.alpha / (R)p.r;
   a.alpha_v = (R)p.alpha_v; a.r_v = (R)p.r_v; a.v0 = (R)p.v0;
   a.alpha_a = (R)p.alpha_a; a.r_a = (R)p.r_a; a.a0 = (R)p.a0;
   a.step = p.step;
@@ -163,10 +175,11 @@ int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const 
   a.cost = static_cast<R *>(d_cost);
   a.grad = static_cast<R *>(d_grad);
   a.B = B; a.m = m; a.t_stride = t_stride;
-  const int waves = auto_waves(c, m);
+  int waves, spl;
+  launch_geometry(c, B, m, &waves, &spl);
   if (gtop_eval_smem_bytes(m, waves, sizeof(R)) > 160 * 1024)
     return fail(c, GTOP_ERR_INVALID, "m too large for one workgroup's LDS");
-  HIPCHK(c, gtop_launch_eval<R>(a, waves, c->prm.enable_dyn != 0, 1 << 20, stream));
+  HIPCHK(c, gtop_launch_eval<R>(a, waves, spl, c->prm.enable_dyn != 0, 1 << 20, stream));
   return GTOP_OK;
 }
 
@@ -460,10 +473,14 @@ int gtop_clear_cost_curve(gtop_ctx *c) {
   return GTOP_OK;
 }
 
-int gtop_set_waves_per_block(gtop_ctx *c, int waves) {
+int gtop_set_launch_geometry(gtop_ctx *c, int waves, int samples_per_lane) {
   if (!c) return GTOP_ERR_INVALID;
   if (waves < 0 || waves > 8) return fail(c, GTOP_ERR_INVALID, "waves per block must be 0 (auto) .. 8");
+  const int s = samples_per_lane;
+  if (!(s == 0 || s == 1 || s == 2 || s == 3 || s == 5 || s == 6))
+    return fail(c, GTOP_ERR_INVALID, "samples per lane must be 0 (auto), 1, 2, 3, 5 or 6");
   c->waves = waves;
+  c->spl = s;
   return GTOP_OK;
 }
 

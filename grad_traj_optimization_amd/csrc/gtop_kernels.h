@@ -22,17 +22,22 @@ struct GtopKernelArgs {
   // shared distance field (HBM, z fastest) — SDFMap fields, sdf_map.h:13-23
   const R *sdf;
   int nx, ny, nz;
-  R origin[3], min_range[3], max_range[3];
+  R origin[3];
+  R lo[3], hi[3];   // min_range + 1e-4, max_range - 1e-4  (isInMap, sdf_map.cpp:55-69)
   R res, res_inv;
   // parameters — grad_traj_optimizer.cpp:5-32
-  R ws, wc, alpha, r, d0, alpha_v, r_v, v0, alpha_a, r_a, a0;
+  R ws, wc, alpha, d0, alpha_v, r_v, v0, alpha_a, r_a, a0;
+  R inv_r, alpha_over_r;   // 1/r, alpha/r  (:509, :514)
   int step;
 };
 
 size_t gtop_eval_smem_bytes(int m, int waves, size_t elem);
 
+// spl = samples per lane (1, 2, 3, 5 or 6); a wavefront then holds
+// gtop_eval_segments_per_wave(spl) segments.
+int gtop_eval_segments_per_wave(int spl);
 template <typename R>
-hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, bool dyn,
+hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
                             int max_blocks, hipStream_t stream);
 
 hipError_t gtop_launch_f64_to_f32(const double *src, float *dst, size_t nelem,

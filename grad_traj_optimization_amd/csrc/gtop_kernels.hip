@@ -60,27 +60,24 @@ __device__ __forceinline__ float round_through_float(float v) { return v; }
 // SDFMap::getDistWithGradTrilinear, src/sdf_map.cpp:185-242.
 // Out of map (src/sdf_map.cpp:55-69, :187): dist = -1; the reference leaves
 // grad uninitialised there, this build defines it as 0.
+// Branch-free: the corner indices are clamped anyway (:166-174), so the loads
+// are always in bounds and the out-of-map case is a final select.
 template <typename R>
 __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R pz,
                                        R &gx, R &gy, R &gz) {
-  const R eps = (R)1e-4;
-  bool out = (px < a.min_range[0] + eps) | (py < a.min_range[1] + eps) |
-             (pz < a.min_range[2] + eps) | (px > a.max_range[0] - eps) |
-             (py > a.max_range[1] - eps) | (pz > a.max_range[2] - eps);
-  if (out) {
-    gx = gy = gz = (R)0;
-    return (R)-1;
-  }
+  const bool out = (px < a.lo[0]) | (py < a.lo[1]) | (pz < a.lo[2]) |
+                   (px > a.hi[0]) | (py > a.hi[1]) | (pz > a.hi[2]);
   const R res = a.res, rinv = a.res_inv;
   const R half = (R)0.5 * res;
   // posToIndex(pos - 0.5 res)  (:201-204 -> :71-74)
-  const int ix = (int)gfloor(((px - half) - a.origin[0]) * rinv);
-  const int iy = (int)gfloor(((py - half) - a.origin[1]) * rinv);
-  const int iz = (int)gfloor(((pz - half) - a.origin[2]) * rinv);
+  const R fx = gfloor(((px - half) - a.origin[0]) * rinv);
+  const R fy = gfloor(((py - half) - a.origin[1]) * rinv);
+  const R fz = gfloor(((pz - half) - a.origin[2]) * rinv);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
   // indexToPos (:76-78) and diff (:209)
-  const R dx = (px - (((R)ix + (R)0.5) * res + a.origin[0])) * rinv;
-  const R dy = (py - (((R)iy + (R)0.5) * res + a.origin[1])) * rinv;
-  const R dz = (pz - (((R)iz + (R)0.5) * res + a.origin[2])) * rinv;
+  const R dx = (px - ((fx + (R)0.5) * res + a.origin[0])) * rinv;
+  const R dy = (py - ((fy + (R)0.5) * res + a.origin[1])) * rinv;
+  const R dz = (pz - ((fz + (R)0.5) * res + a.origin[2])) * rinv;
 
   // per-axis clamp of the 8 corner indices (:166-174).  z is the fastest
   // axis, so the two z-corners of each (x,y) column are one 2-element load;
@@ -91,14 +88,11 @@ __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R
   const int zb = min(max(iz, 0), nz - 2);
   const bool z_lo = iz < 0, z_hi = iz > nz - 2;
   const R *D = a.sdf;
-  const uint32_t r00 = ((uint32_t)x0 * ny + y0) * nz + zb;
-  const uint32_t r01 = ((uint32_t)x0 * ny + y1) * nz + zb;
-  const uint32_t r10 = ((uint32_t)x1 * ny + y0) * nz + zb;
-  const uint32_t r11 = ((uint32_t)x1 * ny + y1) * nz + zb;
-  const Pair<R> p00 = *reinterpret_cast<const Pair<R> *>(D + r00);
-  const Pair<R> p01 = *reinterpret_cast<const Pair<R> *>(D + r01);
-  const Pair<R> p10 = *reinterpret_cast<const Pair<R> *>(D + r10);
-  const Pair<R> p11 = *reinterpret_cast<const Pair<R> *>(D + r11);
+  const uint32_t row0 = (uint32_t)x0 * ny, row1 = (uint32_t)x1 * ny;
+  const Pair<R> p00 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y0) * nz + zb));
+  const Pair<R> p01 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y1) * nz + zb));
+  const Pair<R> p10 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y0) * nz + zb));
+  const Pair<R> p11 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y1) * nz + zb));
   // values[x][y][z]
   const R v000 = z_hi ? p00.y : p00.x, v001 = z_lo ? p00.x : p00.y;
   const R v010 = z_hi ? p01.y : p01.x, v011 = z_lo ? p01.x : p01.y;
@@ -106,21 +100,24 @@ __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R
   const R v110 = z_hi ? p11.y : p11.x, v111 = z_lo ? p11.x : p11.y;
 
   const R one = (R)1;
-  const R v00 = (one - dx) * v000 + dx * v100;  // :221-224
-  const R v01 = (one - dx) * v001 + dx * v101;
-  const R v10 = (one - dx) * v010 + dx * v110;
-  const R v11 = (one - dx) * v011 + dx * v111;
-  const R v0 = (one - dy) * v00 + dy * v10;     // :226-227
-  const R v1 = (one - dy) * v01 + dy * v11;
-  const R dist = (one - dz) * v0 + dz * v1;     // :229
-  gz = (v1 - v0) * rinv;                        // :231
-  gy = ((one - dz) * (v10 - v00) + dz * (v11 - v01)) * rinv;  // :232-233
-  R g0 = (one - dz) * (one - dy) * (v100 - v000);             // :234-239
-  g0 += (one - dz) * dy * (v110 - v010);
-  g0 += dz * (one - dy) * (v101 - v001);
+  const R ex = one - dx, ey = one - dy, ez = one - dz;
+  const R v00 = ex * v000 + dx * v100;  // :221-224
+  const R v01 = ex * v001 + dx * v101;
+  const R v10 = ex * v010 + dx * v110;
+  const R v11 = ex * v011 + dx * v111;
+  const R v0 = ey * v00 + dy * v10;     // :226-227
+  const R v1 = ey * v01 + dy * v11;
+  const R dist = ez * v0 + dz * v1;     // :229
+  const R gzz = (v1 - v0) * rinv;       // :231
+  const R gyy = (ez * (v10 - v00) + dz * (v11 - v01)) * rinv;  // :232-233
+  R g0 = ez * ey * (v100 - v000);       // :234-239
+  g0 += ez * dy * (v110 - v010);
+  g0 += dz * ey * (v101 - v001);
   g0 += dz * dy * (v111 - v011);
-  gx = g0 * rinv;
-  return dist;
+  gx = out ? (R)0 : g0 * rinv;
+  gy = out ? (R)0 : gyy;
+  gz = out ? (R)0 : gzz;
+  return out ? (R)-1 : dist;
 }
 
 template <typename R>
@@ -131,16 +128,24 @@ __device__ __forceinline__ R wave_sum(R v) {
 }
 
 // One workgroup per trajectory (grid-stride over the batch), NW = blockDim/64
-// wavefronts per workgroup, one 32-lane half-wave per polynomial segment.
-template <typename R, bool DYN>
+// wavefronts.  Each polynomial segment is sampled by LPS = 30/SPL adjacent
+// lanes, SPL samples per lane (sample index = lane-in-segment + j*LPS, so
+// neighbouring lanes gather neighbouring voxels); a wavefront holds 64/LPS
+// segments.  SPL = 3 puts all 6 segments of a "20 control point" trajectory
+// in ONE wavefront (60 of 64 lanes busy); SPL = 1 spreads it over 3
+// wavefronts for small, latency-bound batches.
+template <typename R, bool DYN, int SPL>
 __global__ void __launch_bounds__(512)
 gtop_eval_kernel(const GtopKernelArgs<R> a) {
+  constexpr int LPS = kSamples / SPL;        // lanes per segment
+  constexpr int SPW = 64 / LPS;              // segments per wavefront
+  static_assert(LPS * SPL == kSamples, "SPL must divide 30");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *sm = reinterpret_cast<R *>(smem_raw);
   const int m = a.m, ND = 3 * m + 3, ndp = 3 * m - 3, n = 3 * ndp;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, NW = nthr >> 6;
-  const int half = lane >> 5, li = lane & 31;
+  const int slot = lane / LPS, li = lane - slot * LPS;   // segment slot in this wave, lane in segment
 
   R *dv = sm;              // [3][ND]   d = [Df | dp] per axis (:302-323)
   R *Ts = dv + 3 * ND;     // [m]       segment_time
@@ -149,7 +154,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
   R *csm = Gs + 18 * m;    // [m][3]    jerk cost per (segment, axis)
   R *ccol = csm + 3 * m;   // [m]       wc * collision (+dyn) cost per segment
   R *gseg = ccol + m;      // [m][3][6] derivative-space gradient per segment
-  R *red = gseg + 18 * m;  // [NW][19][65] per-wave transpose-reduction tile
+  R *tt = gseg + 18 * m;   // [m][30]   sample times (:353)
+  R *red = tt + kSamples * m;  // [NW][19][65] per-wave transpose-reduction tile
   R *myred = red + wave * (kRedVals * kRedStride);
 
   const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
@@ -185,16 +191,16 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
       const R p0 = d[o0], v0 = d[o0 + 1], a0 = d[o0 + 2];
       const R pT = d[o1], vT = d[o1 + 1], aT = d[o1 + 2];
       const R T = Ts[s], T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+      const R iT = (R)1 / T, iT3 = iT * iT * iT;
       // closed-form A_s^-1 (rows of A_s: src/qp_generator.cpp:185-195)
       const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
       const R V = (vT - v0 - a0 * T) * T;
       const R A = (aT - a0) * T2;
-      const R c0 = p0, c1 = v0, c2 = (R)0.5 * a0;
-      const R c3 = ((R)10 * P - (R)4 * V + (R)0.5 * A) / T3;
-      const R c4 = ((R)-15 * P + (R)7 * V - A) / T4;
-      const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) / T5;
+      const R c3 = ((R)10 * P - (R)4 * V + (R)0.5 * A) * iT3;
+      const R c4 = ((R)-15 * P + (R)7 * V - A) * (iT3 * iT);
+      const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) * (iT3 * iT * iT);
       R *cf = coef + s * 18 + k * 6;
-      cf[0] = c0; cf[1] = c1; cf[2] = c2; cf[3] = c3; cf[4] = c4; cf[5] = c5;
+      cf[0] = p0; cf[1] = v0; cf[2] = (R)0.5 * a0; cf[3] = c3; cf[4] = c4; cf[5] = c5;
       // jerk Hessian Q_s (src/qp_generator.cpp:226-234): i,j in {3,4,5}
       const R q3 = (R)36 * T * c3 + (R)72 * T2 * c4 + (R)120 * T3 * c5;
       const R q4 = (R)72 * T2 * c3 + (R)192 * T3 * c4 + (R)360 * T4 * c5;
@@ -203,97 +209,128 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
       R *g = Gs + s * 18 + k * 6;             // ws * 2Qc == share of ws*(2Rfp'df + 2Rpp dp) (:330-336)
       g[0] = (R)0; g[1] = (R)0; g[2] = (R)0;
       g[3] = ws * (R)2 * q3; g[4] = ws * (R)2 * q4; g[5] = ws * (R)2 * q5;
-      if (k == 0) ccol[s] = (R)0;
+    }
+    // sample times: `for (t = 1e-3; t < T; t += dt)` (:353) accumulates t by
+    // repeated addition, so one lane per segment replays exactly that.
+    for (int s = (int)nthr - 1 - tid; s < m; s += nthr) {   // highest lanes: the ones idle above
+      const R dt = Ts[s] / (R)30.0;
+      R t = (R)1e-3;
+      R *row = tt + s * kSamples;
+#pragma unroll 6
+      for (int i = 0; i < kSamples; ++i) {
+        row[i] = t;
+        t += dt;
+      }
+      ccol[s] = (R)0;
     }
     __syncthreads();
 
     // ---- phase 2: collision samples (:345-409) ----
     if (do_colli) {
-      for (int s0 = 0; s0 < m; s0 += 2 * NW) {   // block-uniform trip count
-        const int s = s0 + wave * 2 + half;
+      for (int s0 = 0; s0 < m; s0 += SPW * NW) {   // block-uniform trip count
+        const int s = s0 + wave * SPW + slot;
+        const bool seg_ok = (slot < SPW) & (s < m);
+        const int sc = seg_ok ? s : 0;             // clamped: inactive lanes compute on segment 0, then discard
         R acc[kRedVals];
 #pragma unroll
         for (int v = 0; v < kRedVals; ++v) acc[v] = (R)0;
-        if (s < m && li < kSamples) {
-          const R Tseg = Ts[s];
-          const R dt = Tseg / (R)30.0;             // :351
-          R t = (R)1e-3;                           // :353: t accumulates by repeated addition
-          for (int i = 0; i < li; ++i) t += dt;
-          if (t < Tseg) {
-            const R *cf = coef + s * 18;
-            const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-            R pos[3], vel[3], acc3[3];
+        const R Tseg = Ts[sc];
+        const R dt = Tseg / (R)30.0;               // :351
+        const R wdt = wc * dt;
+        R cq[18];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const R *q = cf + 6 * k;
-              // :457-465 / :477-485, same left-to-right sums, then the float round trip
-              pos[k] = round_through_float(q[0] + q[1] * t + q[2] * t2 + q[3] * t3 + q[4] * t4 + q[5] * t5);
-              vel[k] = round_through_float(q[1] + (R)2 * q[2] * t + (R)3 * q[3] * t2 + (R)4 * q[4] * t3 + (R)5 * q[5] * t4);
-              if (DYN)  // :497-502
-                acc3[k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
-            }
-            const R vn = gsqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;  // :358
-            R g3[3];
-            const R dist = sdf_query(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2]);  // :363
-            const R e = gexp(-(dist - a.d0) / a.r);
-            const R cd = a.alpha * e;              // :509
-            const R gd = -(a.alpha / a.r) * e;     // :514
-            R csum = wc * (cd * vn * dt);          // :373, weighted as in :417-418
-            // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
-            R w1[3], w2[3], w3[3];
+        for (int j = 0; j < 18; ++j) cq[j] = coef[sc * 18 + j];
+#pragma unroll 1
+        for (int jj = 0; jj < SPL; ++jj) {
+          const R t = tt[sc * kSamples + li + jj * LPS];
+          const bool live = seg_ok & (t < Tseg);   // the loop condition of :353
+          const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+          R pos[3], vel[3], acc3[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              w1[k] = wc * (gd * g3[k] * cd * vn) * dt;
-              w2[k] = wc * (cd * (vel[k] / vn)) * dt;
-              w3[k] = (R)0;
-            }
-            if (DYN && a.step == 2) {
-              // the block commented out at :383-407, formulas :517-535.  cv/ca
-              // in the gradient are the values left by the LAST axis of the
-              // cost loop, and there is no sign(v) factor — both as written.
-              R cv = (R)0, ca = (R)0;
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                cv = a.alpha_v * gexp((gabs(vel[k]) - a.v0) / a.r_v);
-                ca = a.alpha_a * gexp((gabs(acc3[k]) - a.a0) / a.r_a);
-                csum += (cv + ca) * vn * dt;       // wv = wa = 1 (:412)
-              }
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                const R gv = (a.alpha_v / a.r_v) * gexp((gabs(vel[k]) - a.v0) / a.r_v);
-                const R ga = (a.alpha_a / a.r_a) * gexp((gabs(acc3[k]) - a.a0) / a.r_a);
-                w2[k] += (gv * vn + cv * (vel[k] / vn) + ca * (vel[k] / vn)) * dt;
-                w3[k] = (ga * vn) * dt;            // on T*V*V
-              }
-            }
-            // T = [1,t,..,t^5] (:544-551); T*V = [0,1,2t,3t^2,4t^3,5t^4]; T*V*V = [0,0,2,6t,12t^2,20t^3]
-            const R tv[6] = {(R)1, t, t2, t3, t4, t5};
-            const R td[6] = {(R)0, (R)1, (R)2 * t, (R)3 * t2, (R)4 * t3, (R)5 * t4};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-#pragma unroll
-              for (int j = 0; j < 6; ++j) acc[k * 6 + j] = w1[k] * tv[j] + w2[k] * td[j];
-              if (DYN) {
-                acc[k * 6 + 2] += w3[k] * (R)2;
-                acc[k * 6 + 3] += w3[k] * (R)6 * t;
-                acc[k * 6 + 4] += w3[k] * (R)12 * t2;
-                acc[k * 6 + 5] += w3[k] * (R)20 * t3;
-              }
-            }
-            acc[18] = csum;
+          for (int k = 0; k < 3; ++k) {
+            const R *q = cq + 6 * k;
+            // :457-465 / :477-485, same left-to-right sums, then the float round trip
+            pos[k] = round_through_float(q[0] + q[1] * t + q[2] * t2 + q[3] * t3 + q[4] * t4 + q[5] * t5);
+            vel[k] = round_through_float(q[1] + (R)2 * q[2] * t + (R)3 * q[3] * t2 + (R)4 * q[4] * t3 + (R)5 * q[5] * t4);
+            if (DYN)  // :497-502
+              acc3[k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
           }
+          const R vn = gsqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;  // :358
+          const R ivn = (R)1 / vn;
+          R g3[3];
+          const R dist = sdf_query(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2]);  // :363
+          const R e = gexp((a.d0 - dist) * a.inv_r);   // exp(-(d - d0)/r)
+          const R cd = a.alpha * e;                    // :509
+          const R gd = -a.alpha_over_r * e;            // :514
+          R csum = wdt * (cd * vn);                    // :373, weighted as in :417-418
+          // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
+          const R f1 = wdt * (gd * cd * vn), f2 = wdt * (cd * ivn);
+          R w1[3], w2[3], w3[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            w1[k] = f1 * g3[k];
+            w2[k] = f2 * vel[k];
+            w3[k] = (R)0;
+          }
+          if (DYN && a.step == 2) {
+            // the block commented out at :383-407, formulas :517-535.  cv/ca
+            // in the gradient are the values left by the LAST axis of the
+            // cost loop, and there is no sign(v) factor — both as written.
+            R cv = (R)0, ca = (R)0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              cv = a.alpha_v * gexp((gabs(vel[k]) - a.v0) / a.r_v);
+              ca = a.alpha_a * gexp((gabs(acc3[k]) - a.a0) / a.r_a);
+              csum += (cv + ca) * vn * dt;       // wv = wa = 1 (:412)
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const R gv = (a.alpha_v / a.r_v) * gexp((gabs(vel[k]) - a.v0) / a.r_v);
+              const R ga = (a.alpha_a / a.r_a) * gexp((gabs(acc3[k]) - a.a0) / a.r_a);
+              w2[k] += (gv * vn + cv * (vel[k] * ivn) + ca * (vel[k] * ivn)) * dt;
+              w3[k] = (ga * vn) * dt;            // on T*V*V
+            }
+          }
+          if (!live) {
+            csum = (R)0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w1[k] = w2[k] = w3[k] = (R)0;
+          }
+          // T = [1,t,..,t^5] (:544-551); T*V = [0,1,2t,3t^2,4t^3,5t^4]; T*V*V = [0,0,2,6t,12t^2,20t^3]
+          const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            R *ak = acc + 6 * k;
+            ak[0] += w1[k];
+            ak[1] += w1[k] * t + w2[k];
+            ak[2] += w1[k] * t2 + w2[k] * d2;
+            ak[3] += w1[k] * t3 + w2[k] * d3;
+            ak[4] += w1[k] * t4 + w2[k] * d4;
+            ak[5] += w1[k] * t5 + w2[k] * d5;
+            if (DYN) {
+              ak[2] += w3[k] * (R)2;
+              ak[3] += w3[k] * (R)6 * t;
+              ak[4] += w3[k] * (R)12 * t2;
+              ak[5] += w3[k] * (R)20 * t3;
+            }
+          }
+          acc[18] += csum;
         }
-        // transpose-reduce over the 30 samples of each half-wave through LDS
+        // transpose-reduce over the LPS lanes of each segment through LDS
 #pragma unroll
         for (int v = 0; v < kRedVals; ++v) myred[v * kRedStride + lane] = acc[v];
         __syncthreads();
-        if (s < m && li < kRedVals) {
-          const R *col = myred + li * kRedStride + half * 32;
-          R sum = (R)0;
+        for (int r = lane; r < SPW * kRedVals; r += 64) {
+          const int rs = r / kRedVals, v = r - rs * kRedVals;   // (segment slot, value)
+          const int sr = s0 + wave * SPW + rs;
+          if (sr < m) {
+            const R *col = myred + v * kRedStride + rs * LPS;
+            R sum = (R)0;
 #pragma unroll
-          for (int i = 0; i < kSamples; ++i) sum += col[i];
-          if (li < 18) Gs[s * 18 + li] += sum;
-          else ccol[s] = sum;
+            for (int i = 0; i < LPS; ++i) sum += col[i];
+            if (v < 18) Gs[sr * 18 + v] += sum;
+            else ccol[sr] = sum;
+          }
         }
         __syncthreads();
       }
@@ -303,8 +340,9 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
     for (int w = tid; w < 3 * m; w += nthr) {
       const int s = w / 3;
       const R *g = Gs + w * 6;
-      const R T = Ts[s], T2 = T * T, T3 = T2 * T;
-      const R H3 = g[3] / T3, H4 = g[4] / (T3 * T), H5 = g[5] / (T3 * T2);
+      const R T = Ts[s], T2 = T * T;
+      const R iT = (R)1 / T, iT3 = iT * iT * iT;
+      const R H3 = g[3] * iT3, H4 = g[4] * (iT3 * iT), H5 = g[5] * (iT3 * iT * iT);
       const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
       R *o = gseg + w * 6;   // [p0, pT, v0, vT, a0, aT]
       o[0] = g[0] - ap;
@@ -342,29 +380,46 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
 
 size_t gtop_eval_smem_bytes(int m, int waves, size_t elem) {
   const size_t ND = 3 * (size_t)m + 3;
-  size_t elems = 3 * ND + m + 18 * (size_t)m * 3 + 3 * (size_t)m + m +
+  size_t elems = 3 * ND + m + 18 * (size_t)m * 3 + 3 * (size_t)m + m + (size_t)kSamples * m +
                  (size_t)waves * kRedVals * kRedStride;
   return elems * elem;
 }
 
-template <typename R>
-hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, bool dyn,
-                            int max_blocks, hipStream_t stream) {
-  if (args.B <= 0) return hipSuccess;
-  const size_t smem = gtop_eval_smem_bytes(args.m, waves, sizeof(R));
-  auto kern = dyn ? gtop_eval_kernel<R, true> : gtop_eval_kernel<R, false>;
+int gtop_eval_segments_per_wave(int spl) { return 64 / (kSamples / spl); }
+
+template <typename R, bool DYN>
+static hipError_t launch_spl(const GtopKernelArgs<R> &args, int waves, int spl, int grid, size_t smem,
+                             hipStream_t stream) {
+  void (*kern)(const GtopKernelArgs<R>) = nullptr;
+  switch (spl) {
+    case 1: kern = gtop_eval_kernel<R, DYN, 1>; break;
+    case 2: kern = gtop_eval_kernel<R, DYN, 2>; break;
+    case 3: kern = gtop_eval_kernel<R, DYN, 3>; break;
+    case 5: kern = gtop_eval_kernel<R, DYN, 5>; break;
+    case 6: kern = gtop_eval_kernel<R, DYN, 6>; break;
+    default: return hipErrorInvalidValue;
+  }
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  int grid = args.B < max_blocks ? args.B : max_blocks;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), smem, stream, args);
   return hipGetLastError();
 }
 
-template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, bool, int, hipStream_t);
-template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, bool, int, hipStream_t);
+template <typename R>
+hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
+                            int max_blocks, hipStream_t stream) {
+  if (args.B <= 0) return hipSuccess;
+  const size_t smem = gtop_eval_smem_bytes(args.m, waves, sizeof(R));
+  const int grid = args.B < max_blocks ? args.B : max_blocks;
+  return dyn ? launch_spl<R, true>(args, waves, spl, grid, smem, stream)
+             : launch_spl<R, false>(args, waves, spl, grid, smem, stream);
+}
+
+template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, int, bool, int, hipStream_t);
+template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, int, bool, int, hipStream_t);
 
 // ---------------------------------------------------------------------------
 // fp64 -> fp32 copy of the distance field for the GTOP_F32 path

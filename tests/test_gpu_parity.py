@@ -40,9 +40,28 @@ def test_esdf_bit_exact(scene):
 def test_fp64_parity_host_api(scene, oracle_mod, m, kw):
     mp, ctx, sdf = scene
     b = problem.make_trajectories(24, m, mp, seed=100 + m)
+    ctx.set_launch_geometry(0, 0)
     ctx.set_params(**kw)
     ctx.set_problem(b.T, b.Df)
     c, g = ctx.eval_batch(b.x)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params(**kw))
+    rc, rg = rel_err(c, g, c_ref, g_ref)
+    assert rc <= TOL64 and rg <= TOL64, (rc, rg)
+
+
+@pytest.mark.parametrize("m", [2, 6, 12, 13])
+@pytest.mark.parametrize("spl", [1, 2, 3, 5, 6])
+@pytest.mark.parametrize("waves", [0, 1, 4])
+def test_fp64_parity_every_launch_geometry(scene, oracle_mod, m, spl, waves):
+    """Samples per lane / waves per block only change the work split."""
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(16, m, mp, seed=200 + m)
+    kw = dict(ws=0.0)          # collision term alone: the part the geometry touches
+    ctx.set_launch_geometry(waves, spl)
+    ctx.set_params(**kw)
+    ctx.set_problem(b.T, b.Df)
+    c, g = ctx.eval_batch(b.x)
+    ctx.set_launch_geometry(0, 0)
     c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params(**kw))
     rc, rg = rel_err(c, g, c_ref, g_ref)
     assert rc <= TOL64 and rg <= TOL64, (rc, rg)
