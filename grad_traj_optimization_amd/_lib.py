@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgtop_hip.so")
+# GTOP_HIP_LIB selects another build of the same C-ABI (kernel tuning variants)
+_SO = os.environ.get("GTOP_HIP_LIB") or os.path.join(_HERE, "libgtop_hip.so")
 
 GTOP_F64, GTOP_F32 = 0, 1
 _STATUS = {0: "GTOP_OK", 1: "GTOP_ERR_INVALID", 2: "GTOP_ERR_HIP", 3: "GTOP_ERR_NO_DEVICE",

@@ -33,9 +33,21 @@
 
 namespace {
 
+#ifndef GTOP_SAMPLE_UNROLL
+#define GTOP_SAMPLE_UNROLL 1     // unroll factor of the per-lane sample loop (tuning knob)
+#endif
+#ifdef GTOP_WAVES_PER_EU         // register budget: 512 / GTOP_WAVES_PER_EU VGPRs per lane
+#define GTOP_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(GTOP_WAVES_PER_EU)))
+#else
+#define GTOP_WAVES_PER_EU_ATTR
+#endif
 constexpr int kSamples = 30;     // src/grad_traj_optimizer.cpp:351
 constexpr int kRedVals = 19;     // 18 gradient entries + 1 cost per sample
 constexpr int kRedStride = 65;   // 64 lanes + 1 pad: conflict-free column reads
+#ifndef GTOP_RED_CHUNK
+#define GTOP_RED_CHUNK 19
+#endif
+constexpr int kRedChunk = GTOP_RED_CHUNK;   // values per transpose-reduction pass
 
 template <typename R> struct Pair { R x, y; } __attribute__((packed));
 
@@ -135,7 +147,7 @@ __device__ __forceinline__ R wave_sum(R v) {
 // in ONE wavefront (60 of 64 lanes busy); SPL = 1 spreads it over 3
 // wavefronts for small, latency-bound batches.
 template <typename R, bool DYN, int SPL>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront
@@ -155,8 +167,9 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
   R *ccol = csm + 3 * m;   // [m]       wc * collision (+dyn) cost per segment
   R *gseg = ccol + m;      // [m][3][6] derivative-space gradient per segment
   R *tt = gseg + 18 * m;   // [m][30]   sample times (:353)
-  R *red = tt + kSamples * m;  // [NW][19][65] per-wave transpose-reduction tile
-  R *myred = red + wave * (kRedVals * kRedStride);
+  R *dts = tt + kSamples * m;  // [m]   T_s / 30 (:351)
+  R *red = dts + m;        // [NW][kRedChunk][65] per-wave transpose-reduction tile
+  R *myred = red + wave * (kRedChunk * kRedStride);
 
   const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
   const R wc = a.wc;
@@ -167,13 +180,13 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
     {
       const R *xb = a.x + (size_t)b * n;
       for (int i = tid; i < n; i += nthr) {
-        const int axis = i / ndp, c = i - axis * ndp;
+        const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
         dv[axis * ND + 6 + c] = xb[i];
       }
       const R *dfb = a.Df + (size_t)b * 18;
-      for (int i = tid; i < 18; i += nthr) {
-        const int axis = i / 6, j = i - axis * 6;
-        dv[axis * ND + j] = dfb[i];
+      if (tid < 18) {
+        const int axis = tid / 6, j = tid - axis * 6;
+        dv[axis * ND + j] = dfb[tid];
       }
       const R *tb = a.T + (size_t)b * a.t_stride;
       for (int i = tid; i < m; i += nthr) Ts[i] = tb[i];
@@ -213,7 +226,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
     // sample times: `for (t = 1e-3; t < T; t += dt)` (:353) accumulates t by
     // repeated addition, so one lane per segment replays exactly that.
     for (int s = (int)nthr - 1 - tid; s < m; s += nthr) {   // highest lanes: the ones idle above
-      const R dt = Ts[s] / (R)30.0;
+      const R dt = Ts[s] / (R)30.0;             // :351
+      dts[s] = dt;
       R t = (R)1e-3;
       R *row = tt + s * kSamples;
 #pragma unroll 6
@@ -235,13 +249,16 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
 #pragma unroll
         for (int v = 0; v < kRedVals; ++v) acc[v] = (R)0;
         const R Tseg = Ts[sc];
-        const R dt = Tseg / (R)30.0;               // :351
+        const R dt = dts[sc];
         const R wdt = wc * dt;
-        R cq[18];
-#pragma unroll
-        for (int j = 0; j < 18; ++j) cq[j] = coef[sc * 18 + j];
-#pragma unroll 1
+        int coff = sc * 18;
+#pragma unroll GTOP_SAMPLE_UNROLL
         for (int jj = 0; jj < SPL; ++jj) {
+          // the 18 coefficients are re-read from LDS for every sample (broadcast
+          // reads) instead of living in 36 VGPRs across the loop; the empty asm
+          // keeps the compiler from hoisting them back out.
+          asm volatile("" : "+v"(coff));
+          const R *cq = coef + coff;
           const R t = tt[sc * kSamples + li + jj * LPS];
           const bool live = seg_ok & (t < Tseg);   // the loop condition of :353
           const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
@@ -259,7 +276,9 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
           const R ivn = (R)1 / vn;
           R g3[3];
           const R dist = sdf_query(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2]);  // :363
-          const R e = gexp((a.d0 - dist) * a.inv_r);   // exp(-(d - d0)/r)
+          // samples past the loop bound of :353 and idle lanes contribute nothing:
+          // every term below carries a factor e
+          const R e = live ? gexp((a.d0 - dist) * a.inv_r) : (R)0;   // exp(-(d - d0)/r)
           const R cd = a.alpha * e;                    // :509
           const R gd = -a.alpha_over_r * e;            // :514
           R csum = wdt * (cd * vn);                    // :373, weighted as in :417-418
@@ -291,10 +310,10 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
               w3[k] = (ga * vn) * dt;            // on T*V*V
             }
           }
-          if (!live) {
+          if (DYN && !live) {
             csum = (R)0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) w1[k] = w2[k] = w3[k] = (R)0;
+            for (int k = 0; k < 3; ++k) w2[k] = w3[k] = (R)0;
           }
           // T = [1,t,..,t^5] (:544-551); T*V = [0,1,2t,3t^2,4t^3,5t^4]; T*V*V = [0,0,2,6t,12t^2,20t^3]
           const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;
@@ -316,23 +335,29 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
           }
           acc[18] += csum;
         }
-        // transpose-reduce over the LPS lanes of each segment through LDS
+        // transpose-reduce over the LPS lanes of each segment through LDS, kRedChunk
+        // of the 19 values at a time (keeps the tile at kRedChunk x 65 elements)
 #pragma unroll
-        for (int v = 0; v < kRedVals; ++v) myred[v * kRedStride + lane] = acc[v];
-        __syncthreads();
-        for (int r = lane; r < SPW * kRedVals; r += 64) {
-          const int rs = r / kRedVals, v = r - rs * kRedVals;   // (segment slot, value)
-          const int sr = s0 + wave * SPW + rs;
-          if (sr < m) {
-            const R *col = myred + v * kRedStride + rs * LPS;
-            R sum = (R)0;
+        for (int c0 = 0; c0 < kRedVals; c0 += kRedChunk) {
+          const int cn = (kRedVals - c0) < kRedChunk ? (kRedVals - c0) : kRedChunk;
 #pragma unroll
-            for (int i = 0; i < LPS; ++i) sum += col[i];
-            if (v < 18) Gs[sr * 18 + v] += sum;
-            else ccol[sr] = sum;
+          for (int v = 0; v < kRedChunk; ++v)
+            if (v < cn) myred[v * kRedStride + lane] = acc[c0 + v];
+          __syncthreads();
+          for (int r = lane; r < SPW * cn; r += 64) {
+            const int rs = r / cn, v = r - rs * cn;   // (segment slot, value in chunk)
+            const int sr = s0 + wave * SPW + rs;
+            if (sr < m) {
+              const R *col = myred + v * kRedStride + rs * LPS;
+              R sum = (R)0;
+#pragma unroll
+              for (int i = 0; i < LPS; ++i) sum += col[i];
+              if (c0 + v < 18) Gs[sr * 18 + c0 + v] += sum;
+              else ccol[sr] = sum;
+            }
           }
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
 
@@ -358,7 +383,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
     {
       R *gb = a.grad + (size_t)b * n;
       for (int i = tid; i < n; i += nthr) {
-        const int axis = i / ndp, c = i - axis * ndp;
+        const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
         const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
         const R v = gseg[((wpt - 1) * 3 + axis) * 6 + 2 * der + 1] +   // end of segment wpt-1
                     gseg[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
@@ -380,8 +405,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
 
 size_t gtop_eval_smem_bytes(int m, int waves, size_t elem) {
   const size_t ND = 3 * (size_t)m + 3;
-  size_t elems = 3 * ND + m + 18 * (size_t)m * 3 + 3 * (size_t)m + m + (size_t)kSamples * m +
-                 (size_t)waves * kRedVals * kRedStride;
+  size_t elems = 3 * ND + m + 18 * (size_t)m * 3 + 3 * (size_t)m + m + (size_t)kSamples * m + m +
+                 (size_t)waves * kRedChunk * kRedStride;
   return elems * elem;
 }
 
