@@ -135,9 +135,7 @@ def main():
     while args.steps % G:
         G -= 1
     nbuckets = args.steps // G
-    cost_ring = [torch.zeros(G, hi - lo, dtype=tdtype, device=dev) for _ in range(2)]
     grad = torch.zeros(hi - lo, n, dtype=tdtype, device=dev)
-    gathered = [torch.zeros(world, G, hi - lo, dtype=tdtype, device=dev) for _ in range(2)] if world > 1 else None
 
     # ---- parity gate (rank 0): HIP vs oracle on a subsample of this rank's shard ----
     parity = None
@@ -163,8 +161,18 @@ def main():
             sys.exit(3)
 
     # ---- launch plan: one hipGraph per cost ring buffer, G steps each ----
+    from grad_traj_optimization_amd.distributed import CostGatherPipeline
     stream = torch.cuda.current_stream(dev)
     graphs = None
+
+    def run_bucket_eager(j):
+        for s in range(G):
+            ctx.eval_device(x, Df, T, pipe.cost_ring[j][s], grad)
+
+    def run_bucket_graph(j):
+        graphs[j].replay()
+
+    pipe = CostGatherPipeline(world, rank, G, hi - lo, tdtype, dev, run_bucket_eager)
     launch_mode = "eager"
     if not args.no_graph:
         try:
@@ -172,37 +180,17 @@ def main():
             for j in range(2):
                 gph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gph):
-                    for s in range(G):
-                        ctx.eval_device(x, Df, T, cost_ring[j][s], grad)
+                    run_bucket_eager(j)
                 graphs.append(gph)
+            pipe.run_bucket_fn = run_bucket_graph
             launch_mode = "hipgraph"
         except Exception as e:   # capture unsupported: fall back to eager launches, say so
             print(f"bench.py: graph capture failed ({e}); using eager launches", file=sys.stderr)
             graphs = None
             torch.cuda.synchronize()
-
     if rank == 0:
         log(f"launch mode {launch_mode}, {G} steps per bucket")
-    pending = [None, None]
-
-    def run_bucket(b):
-        j = b & 1
-        if pending[j] is not None:      # ring j is about to be overwritten: its all-gather must be done
-            pending[j].wait()
-            pending[j] = None
-        if graphs is not None:
-            graphs[j].replay()
-        else:
-            for s in range(G):
-                ctx.eval_device(x, Df, T, cost_ring[j][s], grad)
-        if world > 1:
-            pending[j] = dist.all_gather_into_tensor(gathered[j], cost_ring[j], async_op=True)
-
-    def drain():
-        for j in range(2):
-            if pending[j] is not None:
-                pending[j].wait()
-                pending[j] = None
+    run_bucket, drain = pipe.run_bucket, pipe.drain
 
     def barrier():
         if world > 1:
@@ -236,8 +224,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # every rank must now hold every rank's costs of the last bucket
-        last = gathered[(nbuckets - 1) & 1]
-        assert torch.equal(last[rank], cost_ring[(nbuckets - 1) & 1])
+        last = pipe.all_costs(nbuckets - 1)
+        assert torch.equal(last[rank], pipe.cost_ring[(nbuckets - 1) & 1])
 
     if rank == 0:
         log(f"timed region done: {elapsed:.4f} s for {args.steps} steps")

@@ -1,0 +1,43 @@
+"""Shared test scenes (inputs only; no reference text)."""
+import numpy as np
+
+# Scene constants of the reference's only built executable
+# (src/opti_node.cpp:61-99): 40x40x5 m map, origin (-20,-20,0), res 0.2, two
+# walls of obstacle points, 11 waypoints.  Loops are restated with the same
+# floating-point accumulation (x += 0.2) the file uses.
+OPTI_NODE_MAP_SIZE = (40.0, 40.0, 5.0)
+OPTI_NODE_ORIGIN = (-20.0, -20.0, 0.0)
+OPTI_NODE_RES = 0.2
+OPTI_NODE_PATH = np.array([(0, -5, 2), (1, -4, 2), (1, -3, 2), (1, -2, 2), (1, -1, 2), (0, 0, 2),
+                           (-1, 1, 2), (-1, 2, 2), (-1, 3, 2), (-1, 4, 2), (0, 5, 2)], dtype=np.float64)
+
+
+def _frange(start, stop, step, up=True):
+    out, v = [], start
+    while (v <= stop) if up else (v >= stop):
+        out.append(v)
+        v += step
+    return out
+
+
+def opti_node_obstacles():
+    obs = []
+    for x in _frange(0.05, 3.0, 0.2):
+        for y in _frange(2.05, 2.7, 0.2):
+            for z in _frange(0.05, 5.0, 0.2):
+                obs.append((x, y, z))
+    for x in _frange(0.05, -3.0, -0.2, up=False):
+        for y in _frange(-2.05, -2.7, -0.2, up=False):
+            for z in _frange(0.05, 5.0, 0.2):
+                obs.append((x, y, z))
+    return np.array(obs, dtype=np.float64)
+
+
+def rel_err(c, g, c_ref, g_ref):
+    """max_i |c_i - cref_i|/|cref_i| and max_i ||g_i - gref_i||_inf / ||gref_i||_inf."""
+    c, g, c_ref, g_ref = (np.atleast_1d(np.asarray(a, dtype=np.float64)) for a in (c, g, c_ref, g_ref))
+    g = g.reshape(c.shape[0], -1)
+    g_ref = g_ref.reshape(c.shape[0], -1)
+    rc = np.max(np.abs(c - c_ref) / np.abs(c_ref))
+    rg = np.max(np.max(np.abs(g - g_ref), axis=1) / np.max(np.abs(g_ref), axis=1))
+    return float(rc), float(rg)

@@ -1,0 +1,72 @@
+"""The N>1 path on CPU: two gloo ranks shard a batch, evaluate their shards
+(the oracle stands in for the GPU evaluator here — tests only), and the bucketed
+all-gather pipeline of bench.py must leave every rank with every rank's costs,
+identical to a single-rank run (pure partitioning, no reduction)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, B, m, G, nbuckets, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grad_traj_optimization_amd import problem
+    from grad_traj_optimization_amd.distributed import CostGatherPipeline, shard_range
+    from oracle import oracle
+
+    mpc = problem.make_map((24, 24, 16), density=0.04, seed=5)
+    sdf = oracle.Sdf.from_map_size(mpc.origin, mpc.resolution, mpc.map_size)
+    sdf.build_from_occupancy(mpc.occupancy)
+    batch = problem.make_trajectories(B, m, mpc, seed=6, step_len=(0.5, 1.0), margin=0.4)
+    lo, hi = shard_range(B, rank, world)
+    prm = oracle.make_params()
+    calls = {"n": 0}
+
+    def run_bucket(j):
+        for s in range(G):
+            # a different x per step so that stale buffers would be caught
+            xs = batch.x[lo:hi] + 1e-3 * calls["n"]
+            c, _, _ = oracle.eval_batch(batch.T[lo:hi], batch.Df[lo:hi], xs, sdf, prm)
+            pipe.cost_ring[j][s].copy_(torch.from_numpy(c))
+            calls["n"] += 1
+
+    pipe = CostGatherPipeline(world, rank, G, hi - lo, torch.float64, torch.device("cpu"), run_bucket)
+    seen = []
+    for b in range(nbuckets):
+        pipe.run_bucket(b)
+        pipe.drain()
+        seen.append(pipe.all_costs(b).clone())
+    np.save(os.path.join(out_dir, f"costs_rank{rank}.npy"), torch.stack(seen).numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_equals_single_rank(tmp_path):
+    B, m, G, nbuckets = 10, 4, 3, 3
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, B, m, G, nbuckets, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "costs_rank0.npy")   # (nbuckets, world, G, B/world)
+    r1 = np.load(tmp_path / "costs_rank1.npy")
+    assert np.array_equal(r0, r1)                 # every rank holds everything
+    # single-rank reference of the same schedule
+    mp.spawn(_worker, args=(1, port + 1, B, m, G, nbuckets, str(tmp_path)), nprocs=1, join=True)
+    s = np.load(tmp_path / "costs_rank0.npy")     # (nbuckets, 1, G, B)
+    two = np.concatenate([r0[:, 0], r0[:, 1]], axis=-1)
+    assert np.array_equal(two, s[:, 0])           # bit-identical: partitioning only
+
+
+def test_shard_range_partitions_exactly():
+    from grad_traj_optimization_amd.problem import shard_range
+    for B in (1, 7, 1024, 131072):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(B, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
