@@ -91,6 +91,9 @@ def load_library():
         "gtop_eval_batch": (C.c_int, [vp, C.c_int, dp, dp, dp]),
         "gtop_cost_nlopt": (C.c_double, [C.c_uint, dp, dp, vp]),
         "gtop_eval_device": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]),
+        "gtop_default_bounds": (C.c_int, [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_double, dp, dp]),
+        "gtop_optimize_batch": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, dp]),
+        "gtop_optimize_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]),
         "gtop_get_stats": (C.c_int, [vp, C.POINTER(C.c_int64), dp]),
         "gtop_reset_stats": (C.c_int, [vp]),
         "gtop_get_cost_curve": (C.c_int, [vp, dp, dp, C.c_int, ip]),
@@ -247,6 +250,48 @@ class GtopContext:
                                            C.c_void_p(cost.data_ptr()), C.c_void_p(grad.data_ptr()),
                                            C.c_void_p(stream)))
         return cost, grad
+
+    # -- batched optimizer --
+    @staticmethod
+    def default_bounds(waypoints, bos=3.0, vos=8.0, aos=10.0):
+        """(B, m+1, 3) waypoints -> lb, ub of shape (B, n) (opti_node.launch bos/vos/aos)."""
+        wp = _f64(waypoints)
+        B, npts, _ = wp.shape
+        m = npts - 1
+        lb = np.empty((B, 9 * (m - 1)))
+        ub = np.empty_like(lb)
+        rc = load_library().gtop_default_bounds(B, m, _p(wp), bos, vos, aos, _p(lb), _p(ub))
+        if rc != 0:
+            raise GtopError(rc, "gtop_default_bounds")
+        return lb, ub
+
+    def optimize_batch(self, x0, lb, ub, max_evals):
+        """Host arrays; returns (best x, its cost) for the problem of set_problem."""
+        x = _f64(x0).copy()
+        B = x.shape[0]
+        lb, ub = _f64(lb), _f64(ub)
+        assert lb.shape == x.shape == ub.shape
+        cost = np.empty(B)
+        self._chk(self._L.gtop_optimize_batch(self._h, B, _p(x), _p(lb), _p(ub), int(max_evals), _p(cost)))
+        return x, cost
+
+    def optimize_device(self, x, Df, T, lb, ub, max_evals, min_cost=None, stream=None):
+        """torch fp64 CUDA tensors; x is overwritten with the best point."""
+        import torch
+        B, n = x.shape
+        m = n // 9 + 1
+        stride = m if T.dim() == 2 else 0
+        for t in (x, Df, T, lb, ub):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64
+        if min_cost is None:
+            min_cost = torch.empty(B, dtype=torch.float64, device=x.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._chk(self._L.gtop_optimize_device(self._h, B, m, C.c_void_p(x.data_ptr()), C.c_void_p(Df.data_ptr()),
+                                               C.c_void_p(T.data_ptr()), stride, C.c_void_p(lb.data_ptr()),
+                                               C.c_void_p(ub.data_ptr()), int(max_evals),
+                                               C.c_void_p(min_cost.data_ptr()), C.c_void_p(stream)))
+        return x, min_cost
 
     # -- bookkeeping --
     def stats(self):

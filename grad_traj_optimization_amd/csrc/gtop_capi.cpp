@@ -43,6 +43,14 @@ struct gtop_ctx {
   double *d_T = nullptr, *d_Df = nullptr, *d_x = nullptr, *d_cost = nullptr, *d_grad = nullptr;
   size_t cap_T = 0, cap_Df = 0, cap_x = 0, cap_grad = 0, cap_cost = 0;
 
+  // batched optimizer workspace (gtop_optimize_*)
+  double *mma_vec = nullptr;   // 6 x [B][n]
+  double *mma_scal = nullptr;  // 4 x [B]
+  int *mma_int = nullptr;      // 2 x [B]
+  double *mma_f = nullptr, *mma_g = nullptr, *mma_lb = nullptr, *mma_ub = nullptr;
+  size_t cap_mma_vec = 0, cap_mma_scal = 0, cap_mma_int = 0, cap_mma_f = 0, cap_mma_g = 0, cap_mma_lb = 0,
+         cap_mma_ub = 0;
+
   int waves = 0;   // 0 = auto
   int spl = 0;     // samples per lane, 0 = auto
 
@@ -228,7 +236,8 @@ int gtop_destroy(gtop_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   release_sdf(c);
   void *bufs[] = {c->occ, c->tmp1, c->tmp2, c->zws, c->d_pts, c->vws,
-                  c->d_T, c->d_Df, c->d_x, c->d_cost, c->d_grad};
+                  c->d_T, c->d_Df, c->d_x, c->d_cost, c->d_grad,
+                  c->mma_vec, c->mma_scal, c->mma_int, c->mma_f, c->mma_g, c->mma_lb, c->mma_ub};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -437,6 +446,96 @@ int gtop_eval_device(gtop_ctx *c, int dtype, int B, int m, const void *d_x, cons
     return launch_eval<float>(c, c->sdf32, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
   }
   return fail(c, GTOP_ERR_INVALID, "bad dtype");
+}
+
+// Batched optimizer: max_evals lock-step iterations of {cost/gradient kernel,
+// MMA update kernel} on `stream`; no host synchronisation inside.
+int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df, const void *d_T,
+                         int time_stride, const void *d_lb, const void *d_ub, int max_evals, void *d_minf,
+                         void *hip_stream) {
+  if (!c) return GTOP_ERR_INVALID;
+  int rc = check_eval_state(c);
+  if (rc) return rc;
+  if (B < 0 || m < 2 || max_evals < 1 || (time_stride != 0 && time_stride != m))
+    return fail(c, GTOP_ERR_INVALID, "optimize_device: need B >= 0, m >= 2, max_evals >= 1, time_stride in {0, m}");
+  if (B == 0) return GTOP_OK;
+  if (!d_x || !d_Df || !d_T || !d_lb || !d_ub) return fail(c, GTOP_ERR_INVALID, "optimize_device: NULL buffer");
+  if (!c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const size_t n = 9 * (size_t)(m - 1), bn = (size_t)B * n;
+  if ((rc = ensure(c, &c->mma_vec, &c->cap_mma_vec, 6 * bn))) return rc;
+  if ((rc = ensure(c, &c->mma_scal, &c->cap_mma_scal, 4 * (size_t)B))) return rc;
+  if ((rc = ensure(c, &c->mma_int, &c->cap_mma_int, 2 * (size_t)B))) return rc;
+  if ((rc = ensure(c, &c->mma_f, &c->cap_mma_f, (size_t)B))) return rc;
+  if ((rc = ensure(c, &c->mma_g, &c->cap_mma_g, bn))) return rc;
+  GtopMmaState st;
+  st.x = c->mma_vec; st.xcur = st.x + bn; st.xprev = st.xcur + bn; st.xprevprev = st.xprev + bn;
+  st.dfdx = st.xprevprev + bn; st.sigma = st.dfdx + bn;
+  st.lb = static_cast<const double *>(d_lb);
+  st.ub = static_cast<const double *>(d_ub);
+  st.rho = c->mma_scal; st.minf = st.rho + B; st.gval = st.minf + B; st.wval = st.gval + B;
+  st.k = c->mma_int; st.state = st.k + B;
+  HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
+  for (int it = 0; it < max_evals; ++it) {
+    if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s)))
+      return rc;
+    HIPCHK(c, gtop_launch_mma_update(st, B, (int)n, c->mma_f, c->mma_g, s));
+  }
+  HIPCHK(c, hipMemcpyAsync(d_x, st.x, bn * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (d_minf) HIPCHK(c, hipMemcpyAsync(d_minf, st.minf, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s));
+  return GTOP_OK;
+}
+
+int gtop_optimize_batch(gtop_ctx *c, int B, double *x, const double *lb, const double *ub, int max_evals,
+                        double *min_cost) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (c->B == 0) return fail(c, GTOP_ERR_STATE, "gtop_set_problem has not been called");
+  if (B < 1 || B > c->B || !x || !lb || !ub || max_evals < 1)
+    return fail(c, GTOP_ERR_INVALID, "optimize_batch: 1 <= B <= problem batch, non-NULL buffers, max_evals >= 1");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = 9 * (size_t)(c->m - 1), bn = (size_t)B * n;
+  int rc;
+  if ((rc = ensure(c, &c->mma_lb, &c->cap_mma_lb, bn))) return rc;
+  if ((rc = ensure(c, &c->mma_ub, &c->cap_mma_ub, bn))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_x, x, bn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->mma_lb, lb, bn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->mma_ub, ub, bn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if ((rc = gtop_optimize_device(c, B, c->m, c->d_x, c->d_Df, c->d_T, c->t_stride, c->mma_lb, c->mma_ub,
+                                 max_evals, c->d_cost, c->stream)))
+    return rc;
+  HIPCHK(c, hipMemcpyAsync(x, c->d_x, bn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (min_cost)
+    HIPCHK(c, hipMemcpyAsync(min_cost, c->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
+// grad_traj_optimizer.cpp:151-179
+int gtop_default_bounds(int B, int m, const double *path, double bos, double vos, double aos, double *lb,
+                        double *ub) {
+  if (B < 1 || m < 2 || !path || !lb || !ub) return GTOP_ERR_INVALID;
+  const int num_dp = 3 * m - 3;
+  const size_t n = 3 * (size_t)num_dp;
+  for (int b = 0; b < B; ++b) {
+    const double *p = path + (size_t)b * (m + 1) * 3;
+    double *l = lb + (size_t)b * n, *u = ub + (size_t)b * n;
+    for (int i = 0; i < num_dp; ++i)
+      for (int a = 0; a < 3; ++a) {
+        const size_t j = (size_t)i + (size_t)a * num_dp;
+        if (i % 3 == 0) {
+          l[j] = p[(i / 3 + 1) * 3 + a] - bos;
+          u[j] = p[(i / 3 + 1) * 3 + a] + bos;
+        } else if (i % 3 == 1) {
+          l[j] = -vos;
+          u[j] = vos;
+        } else {
+          l[j] = -aos;
+          u[j] = aos;
+        }
+      }
+  }
+  return GTOP_OK;
 }
 
 int gtop_get_stats(const gtop_ctx *c, int64_t *iter_num, double *total_time) {

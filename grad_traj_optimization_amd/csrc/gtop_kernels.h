@@ -62,4 +62,15 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, double 
                                   double *dist, int *vws, double *zws, size_t ws_lines,
                                   hipStream_t stream);
 
+// ---- batched CCSA-MMA optimizer state (gtop_mma.hip), all fp64, [B][n] / [B] ----
+struct GtopMmaState {
+  double *x, *xcur, *xprev, *xprevprev, *dfdx, *sigma;   // [B][n]
+  const double *lb, *ub;                                  // [B][n]
+  double *rho, *minf, *gval, *wval;                       // [B]
+  int *k, *state;                                         // [B]
+};
+hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const double *x0, hipStream_t stream);
+hipError_t gtop_launch_mma_update(const GtopMmaState &st, int B, int n, const double *fcur, const double *gcur,
+                                  hipStream_t stream);
+
 #endif  // GTOP_KERNELS_H_

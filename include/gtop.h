@@ -142,6 +142,31 @@ int gtop_eval_device(gtop_ctx *ctx, int dtype, int B, int m, const void *d_x,
                      const void *d_Df, const void *d_T, int time_stride,
                      void *d_cost, void *d_grad, void *hip_stream);
 
+/* ---- batched optimizer driver -------------------- */
+
+/* Box bounds of GradTrajOptimizer::optimizeTrajectory
+ * (src/grad_traj_optimizer.cpp:151-179): waypoint positions +-bos, velocities
+ * +-vos, accelerations +-aos.  path: B x (m+1) x 3 waypoints; lb/ub: B x n.
+ * Pure host helper (no context, no device). */
+int gtop_default_bounds(int B, int m, const double *path, double bos,
+                        double vos, double aos, double *lb, double *ub);
+
+/* B independent bound-constrained CCSA-MMA solves in lock step on the device:
+ * what B calls of nlopt::opt::optimize with algorithm 24 (LD_MMA) do one
+ * after another in the reference (src/grad_traj_optimizer.cpp:137-195), here
+ * as max_evals rounds of {cost/gradient kernel, optimizer update kernel}.  The
+ * stop rule is an evaluation count (the reference stops on wall-clock
+ * maxtime, :144-148, which is not reproducible).  x: in = start point
+ * (:182-187), out = best point found; min_cost: its cost.  fp64.
+ * gtop_optimize_batch uses the problem of gtop_set_problem and host buffers;
+ * gtop_optimize_device takes device pointers and only enqueues work. */
+int gtop_optimize_batch(gtop_ctx *ctx, int B, double *x, const double *lb,
+                        const double *ub, int max_evals, double *min_cost);
+int gtop_optimize_device(gtop_ctx *ctx, int B, int m, void *d_x,
+                         const void *d_Df, const void *d_T, int time_stride,
+                         const void *d_lb, const void *d_ub, int max_evals,
+                         void *d_min_cost, void *hip_stream);
+
 /* ---- bookkeeping the reference keeps inside the callback ------------ */
 
 /* iter_num and total_time (src/grad_traj_optimizer.cpp:284, :436); reset as
