@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--bucket", type=int, default=50, help="steps per graph / per cost all-gather")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra workloads reported under 'extras'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--waves", type=int, default=0, help="waves per trajectory block (0 = auto)")
     ap.add_argument("--spl", type=int, default=0, help="samples per lane (0 = auto)")
@@ -261,12 +262,72 @@ def main():
             "parity": parity,
             "esdf_build_s": esdf_s,
         }
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(args, ctx, batch, mp, x, Df, T, tdtype, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, batch, mp, ctx)
         print(json.dumps(out), flush=True)
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def _time_evals(ctx, x, Df, T, reps):
+    """us per launch of gtop_eval_device on torch's current stream (HIP events)."""
+    import torch
+    cost, grad = ctx.eval_device(x, Df, T)
+    for _ in range(5):
+        ctx.eval_device(x, Df, T, cost, grad)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ctx.eval_device(x, Df, T, cost, grad)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def extras(args, ctx, batch, mp, x, Df, T, tdtype, dev):
+    """Not part of `value`: (1) the other single-GPU BASELINE.json workloads on the
+    same map (eager launches, HIP-event time per launch), (2) the batched
+    optimizer driver on the bench batch."""
+    import torch
+    from grad_traj_optimization_amd import problem
+    import grad_traj_optimization_amd as gtop
+    out = {"workloads": []}
+    if args.grid == 200 and args.segments == 6:
+        big = problem.make_trajectories(16384, 6, mp, seed=7)
+        for dt, name in ((torch.float32, "f32"), (torch.float64, "f64")):
+            xb = torch.tensor(big.x, dtype=dt, device=dev)
+            Dfb = torch.tensor(big.Df.reshape(-1, 18), dtype=dt, device=dev)
+            Tb = torch.tensor(big.T, dtype=dt, device=dev)
+            us = _time_evals(ctx, xb, Dfb, Tb, 200)
+            bpe = algorithmic_bytes(6, 4 if name == "f32" else 8)
+            out["workloads"].append({
+                "workload": f"B=16384 x 6 segments, 200^3 SDF, {name}" + (" [BASELINE.json configs[2]]" if name == "f32" else ""),
+                "us_per_launch": us, "evals_per_s": 16384 / (us * 1e-6),
+                "roofline_frac": 16384 * bpe / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+    if tdtype == torch.float64:
+        lb, ub = gtop.GtopContext.default_bounds(batch.waypoints[:x.shape[0]])
+        lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
+        evals = 50
+        xo = x.clone()
+        ctx.optimize_device(xo, Df, T, lbt, ubt, evals)       # warm-up
+        torch.cuda.synchronize()
+        xo = x.clone()
+        t0 = time.perf_counter()
+        _, cmin = ctx.optimize_device(xo, Df, T, lbt, ubt, evals)
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        c0, _ = ctx.eval_device(x, Df, T)
+        torch.cuda.synchronize()
+        out["optimizer"] = {
+            "what": "lock-step batched CCSA-MMA on the device (replaces per-problem NLopt LD_MMA)",
+            "batch": int(x.shape[0]), "evals_per_trajectory": evals, "seconds": dt_s,
+            "trajectories_optimized_per_s": x.shape[0] / dt_s,
+            "median_cost_ratio_after_vs_before": float(torch.median(cmin / c0).item())}
+    return out
 
 
 def cpu_baseline(args, batch, mp, ctx):
