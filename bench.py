@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra workloads reported under 'extras'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-sort", action="store_true",
+                    help="keep the generator's random batch order (default: Morton-ordered for L2 locality)")
     ap.add_argument("--waves", type=int, default=0, help="waves per trajectory block (0 = auto)")
     ap.add_argument("--spl", type=int, default=0, help="samples per lane (0 = auto)")
     return ap.parse_args()
@@ -126,6 +128,8 @@ def main():
     if rank == 0:
         log(f"map {args.grid}^3 built on GPU in {esdf_s:.3f} s")
     batch = problem.make_trajectories(B_total, m, mp, seed=1)
+    if not args.no_sort:   # one-time setup, like setPath: trajectories that run together read the same map region
+        batch = problem.permute(batch, problem.spatial_order(batch.waypoints, mp.origin, mp.map_size))
     lo, hi = problem.shard_range(B_total, rank, world)
     x = torch.tensor(batch.x[lo:hi], dtype=tdtype, device=dev)
     Df = torch.tensor(batch.Df[lo:hi].reshape(-1, 18), dtype=tdtype, device=dev)

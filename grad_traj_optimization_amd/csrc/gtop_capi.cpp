@@ -53,6 +53,7 @@ struct gtop_ctx {
 
   int waves = 0;   // 0 = auto
   int spl = 0;     // samples per lane, 0 = auto
+  int auto_spl_large = 6;   // what auto picks for B >= 4096 (m = 6: two trajectories per wavefront)
 
   // bookkeeping of the callback (grad_traj_optimizer.cpp:284, :436, :439-447)
   int64_t iter_num = 0;
@@ -135,20 +136,26 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
   return GTOP_OK;
 }
 
-// Launch geometry.  spl (samples per lane) sets how many segments one
-// wavefront holds (2, 4, 6, 10, 12 for spl 1, 2, 3, 5, 6).  Auto: large
-// batches are throughput-bound -> fewest wavefronts per trajectory (spl 3,
-// or 6 when m > 6); small batches are latency-bound -> spread a trajectory
-// over more wavefronts (spl 1).
-void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl) {
+// Launch geometry.  spl (samples per lane, a divisor of 30) sets how many
+// segments one wavefront holds (spw = 2, 4, 6, 10, 12, 21, 32, 64 for spl =
+// 1, 2, 3, 5, 6, 10, 15, 30); a workgroup of `waves` wavefronts then owns
+// tpb = floor(waves*spw / m) whole trajectories (at least 1).  Auto: large
+// batches are throughput-bound -> several trajectories per wavefront, which
+// amortises the few-lane phases; small batches are latency-bound -> spread one
+// trajectory over more wavefronts.
+void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb) {
   int s = c->spl;
-  if (s == 0) s = (B >= 4096) ? (m > 6 ? 6 : 3) : 1;
+  if (s == 0) s = (B >= 4096) ? c->auto_spl_large : 1;
   const int spw = gtop_eval_segments_per_wave(s);
-  int w = c->waves > 0 ? c->waves : (m + spw - 1) / spw;
+  int w = c->waves > 0 ? c->waves : (spw >= m ? 1 : (m + spw - 1) / spw);
   if (w < 1) w = 1;
   if (w > 8) w = 8;
+  int t = (w * spw) / m;
+  if (t < 1) t = 1;
+  if (t > 16) t = 16;
   *waves = w;
   *spl = s;
+  *tpb = t;
 }
 
 template <typename R>
@@ -183,9 +190,11 @@ int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const 
   a.cost = static_cast<R *>(d_cost);
   a.grad = static_cast<R *>(d_grad);
   a.B = B; a.m = m; a.t_stride = t_stride;
-  int waves, spl;
-  launch_geometry(c, B, m, &waves, &spl);
-  if (gtop_eval_smem_bytes(m, waves, sizeof(R)) > 160 * 1024)
+  int waves, spl, tpb;
+  launch_geometry(c, B, m, &waves, &spl, &tpb);
+  while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, sizeof(R)) > 64 * 1024) --tpb;
+  a.tpb = tpb;
+  if (gtop_eval_smem_bytes(m, waves, tpb, sizeof(R)) > 160 * 1024)
     return fail(c, GTOP_ERR_INVALID, "m too large for one workgroup's LDS");
   HIPCHK(c, gtop_launch_eval<R>(a, waves, spl, c->prm.enable_dyn != 0, 1 << 20, stream));
   return GTOP_OK;
@@ -576,8 +585,8 @@ int gtop_set_launch_geometry(gtop_ctx *c, int waves, int samples_per_lane) {
   if (!c) return GTOP_ERR_INVALID;
   if (waves < 0 || waves > 8) return fail(c, GTOP_ERR_INVALID, "waves per block must be 0 (auto) .. 8");
   const int s = samples_per_lane;
-  if (!(s == 0 || s == 1 || s == 2 || s == 3 || s == 5 || s == 6))
-    return fail(c, GTOP_ERR_INVALID, "samples per lane must be 0 (auto), 1, 2, 3, 5 or 6");
+  if (!(s == 0 || (s >= 1 && s <= 30 && 30 % s == 0)))
+    return fail(c, GTOP_ERR_INVALID, "samples per lane must be 0 (auto) or a divisor of 30");
   c->waves = waves;
   c->spl = s;
   return GTOP_OK;

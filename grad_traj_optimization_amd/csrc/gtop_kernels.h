@@ -19,6 +19,7 @@ struct GtopKernelArgs {
   R *cost;       // [B]
   R *grad;       // [B][n]
   int B, m, t_stride;
+  int tpb;       // trajectories per workgroup (>= 1)
   // shared distance field (HBM, z fastest) — SDFMap fields, sdf_map.h:13-23
   const R *sdf;
   int nx, ny, nz;
@@ -31,9 +32,9 @@ struct GtopKernelArgs {
   int step;
 };
 
-size_t gtop_eval_smem_bytes(int m, int waves, size_t elem);
+size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem);
 
-// spl = samples per lane (1, 2, 3, 5 or 6); a wavefront then holds
+// spl = samples per lane (a divisor of 30); a wavefront then holds
 // gtop_eval_segments_per_wave(spl) segments.
 int gtop_eval_segments_per_wave(int spl);
 template <typename R>

@@ -50,6 +50,8 @@ constexpr int kRedStride = 65;   // 64 lanes + 1 pad: conflict-free column reads
 constexpr int kRedChunk = GTOP_RED_CHUNK;   // values per transpose-reduction pass
 
 template <typename R> struct Pair { R x, y; } __attribute__((packed));
+template <typename R> constexpr bool kIsF32 = false;
+template <> constexpr bool kIsF32<float> = true;
 
 template <typename R> __device__ __forceinline__ R gexp(R v);
 template <> __device__ __forceinline__ double gexp<double>(double v) { return exp(v); }
@@ -139,13 +141,177 @@ __device__ __forceinline__ R wave_sum(R v) {
   return v;
 }
 
-// One workgroup per trajectory (grid-stride over the batch), NW = blockDim/64
-// wavefronts.  Each polynomial segment is sampled by LPS = 30/SPL adjacent
-// lanes, SPL samples per lane (sample index = lane-in-segment + j*LPS, so
-// neighbouring lanes gather neighbouring voxels); a wavefront holds 64/LPS
-// segments.  SPL = 3 puts all 6 segments of a "20 control point" trajectory
-// in ONE wavefront (60 of 64 lanes busy); SPL = 1 spreads it over 3
-// wavefronts for small, latency-bound batches.
+// ---------------------------------------------------------------------------
+// Packed-fp32 sample path.  On gfx950 a wave64 VALU instruction occupies its
+// SIMD for 4 cycles whether it is fp64, scalar fp32 or PACKED fp32
+// (v_pk_fma_f32 & co.: two fp32 per lane) — measured, tools/ubench/pk_rate.hip.
+// So the fp32 path evaluates TWO samples of a lane at once in float2 registers:
+// the arithmetic (polynomials, trilinear blend, weights, the 18 accumulators)
+// issues as v_pk_* and costs half; only index/clamp/load/select and the
+// transcendental ops stay per component.
+// ---------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+
+// two SDFMap::getDistWithGradTrilinear queries (src/sdf_map.cpp:185-242)
+__device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 px, f2 py, f2 pz,
+                                             f2 &gx, f2 &gy, f2 &gz, bool &outA, bool &outB) {
+  outA = (px.x < a.lo[0]) | (py.x < a.lo[1]) | (pz.x < a.lo[2]) | (px.x > a.hi[0]) | (py.x > a.hi[1]) | (pz.x > a.hi[2]);
+  outB = (px.y < a.lo[0]) | (py.y < a.lo[1]) | (pz.y < a.lo[2]) | (px.y > a.hi[0]) | (py.y > a.hi[1]) | (pz.y > a.hi[2]);
+  const f2 res = splat(a.res), rinv = splat(a.res_inv), half = splat(0.5f * a.res);
+  const f2 ox = splat(a.origin[0]), oy = splat(a.origin[1]), oz = splat(a.origin[2]);
+  f2 fx = ((px - half) - ox) * rinv, fy = ((py - half) - oy) * rinv, fz = ((pz - half) - oz) * rinv;
+  fx = (f2){floorf(fx.x), floorf(fx.y)};
+  fy = (f2){floorf(fy.x), floorf(fy.y)};
+  fz = (f2){floorf(fz.x), floorf(fz.y)};
+  const f2 h = splat(0.5f);
+  const f2 dx = (px - ((fx + h) * res + ox)) * rinv;
+  const f2 dy = (py - ((fy + h) * res + oy)) * rinv;
+  f2 dz = (pz - ((fz + h) * res + oz)) * rinv;
+
+  const int nx = a.nx, ny = a.ny, nz = a.nz;
+  const float *D = a.sdf;
+  Pair<float> p00[2], p01[2], p10[2], p11[2];
+  bool zflat[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int ix = (int)(c ? fx.y : fx.x), iy = (int)(c ? fy.y : fy.x), iz = (int)(c ? fz.y : fz.x);
+    const int x0 = min(max(ix, 0), nx - 1), x1 = min(max(ix + 1, 0), nx - 1);
+    const int y0 = min(max(iy, 0), ny - 1), y1 = min(max(iy + 1, 0), ny - 1);
+    const int zb = min(max(iz, 0), nz - 2);
+    const uint32_t row0 = (uint32_t)x0 * ny, row1 = (uint32_t)x1 * ny;
+    p00[c] = *reinterpret_cast<const Pair<float> *>(D + ((row0 + y0) * nz + zb));
+    p01[c] = *reinterpret_cast<const Pair<float> *>(D + ((row0 + y1) * nz + zb));
+    p10[c] = *reinterpret_cast<const Pair<float> *>(D + ((row1 + y0) * nz + zb));
+    p11[c] = *reinterpret_cast<const Pair<float> *>(D + ((row1 + y1) * nz + zb));
+    // z border (:166-174): both z-corners clamp to the same voxel.  With the
+    // pair (D[zb], D[zb+1]) loaded, that is dz := 0 (iz = -1) or 1 (iz = nz-1)
+    // and a zero z-gradient.
+    const bool lo = iz < 0, hi = iz > nz - 2;
+    zflat[c] = lo | hi;
+    const float dzc = lo ? 0.0f : (hi ? 1.0f : (c ? dz.y : dz.x));
+    if (c) dz.y = dzc; else dz.x = dzc;
+  }
+  const f2 v000 = {p00[0].x, p00[1].x}, v001 = {p00[0].y, p00[1].y};
+  const f2 v010 = {p01[0].x, p01[1].x}, v011 = {p01[0].y, p01[1].y};
+  const f2 v100 = {p10[0].x, p10[1].x}, v101 = {p10[0].y, p10[1].y};
+  const f2 v110 = {p11[0].x, p11[1].x}, v111 = {p11[0].y, p11[1].y};
+  const f2 one = splat(1.0f);
+  const f2 ex = one - dx, ey = one - dy, ez = one - dz;
+  const f2 v00 = ex * v000 + dx * v100;  // :221-224
+  const f2 v01 = ex * v001 + dx * v101;
+  const f2 v10 = ex * v010 + dx * v110;
+  const f2 v11 = ex * v011 + dx * v111;
+  const f2 v0 = ey * v00 + dy * v10;     // :226-227
+  const f2 v1 = ey * v01 + dy * v11;
+  f2 dist = ez * v0 + dz * v1;           // :229
+  gz = (v1 - v0) * rinv;                 // :231
+  gy = (ez * (v10 - v00) + dz * (v11 - v01)) * rinv;  // :232-233
+  f2 g0 = ez * ey * (v100 - v000);       // :234-239
+  g0 += ez * dy * (v110 - v010);
+  g0 += dz * ey * (v101 - v001);
+  g0 += dz * dy * (v111 - v011);
+  gx = g0 * rinv;
+  if (zflat[0]) gz.x = 0.0f;
+  if (zflat[1]) gz.y = 0.0f;
+  return dist;
+}
+
+// Two samples (t.x, t.y) of one segment: everything phase 2 does per sample
+// (src/grad_traj_optimizer.cpp:353-381), accumulated component-wise into
+// acc2[19]; the caller adds the two components after its loop.
+template <bool DYN>
+__device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, const float *cq, f2 t,
+                                                bool liveA, bool liveB, float wdt, float dt, f2 (&acc2)[kRedVals]) {
+  const f2 t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+  f2 pos[3], vel[3], acc3[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float *q = cq + 6 * k;
+    pos[k] = splat(q[0]) + splat(q[1]) * t + splat(q[2]) * t2 + splat(q[3]) * t3 + splat(q[4]) * t4 + splat(q[5]) * t5;
+    vel[k] = splat(q[1]) + splat(2.0f * q[2]) * t + splat(3.0f * q[3]) * t2 + splat(4.0f * q[4]) * t3 + splat(5.0f * q[5]) * t4;
+    if (DYN) acc3[k] = splat(2.0f * q[2]) + splat(6.0f * q[3]) * t + splat(12.0f * q[4]) * t2 + splat(20.0f * q[5]) * t3;
+  }
+  const f2 v2 = vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2];
+  const f2 vn = (f2){__builtin_amdgcn_sqrtf(v2.x), __builtin_amdgcn_sqrtf(v2.y)} + splat(1e-5f);   // :358
+  const f2 ivn = {__builtin_amdgcn_rcpf(vn.x), __builtin_amdgcn_rcpf(vn.y)};
+  f2 g3[3];
+  bool outA, outB;
+  f2 dist = sdf_query_pair(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2], outA, outB);   // :363
+  if (outA) dist.x = -1.0f;   // out of map (sdf_map.cpp:187): dist = -1, grad := 0
+  if (outB) dist.y = -1.0f;
+  const f2 arg = (splat(a.d0) - dist) * splat(a.inv_r);
+  f2 e = {__expf(arg.x), __expf(arg.y)};          // exp(-(d - d0)/r)
+  if (!liveA) e.x = 0.0f;                          // past the loop bound of :353 / idle lane
+  if (!liveB) e.y = 0.0f;
+  const f2 cd = splat(a.alpha) * e;                // :509
+  const f2 gd = splat(-a.alpha_over_r) * e;        // :514
+  f2 csum = splat(wdt) * (cd * vn);                // :373
+  f2 f1 = splat(wdt) * (gd * cd * vn);
+  const f2 f2_ = splat(wdt) * (cd * ivn);
+  if (outA) f1.x = 0.0f;
+  if (outB) f1.y = 0.0f;
+  f2 w1[3], w2[3], w3[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    w1[k] = f1 * g3[k];
+    w2[k] = f2_ * vel[k];
+    w3[k] = splat(0.0f);
+  }
+  if (DYN && a.step == 2) {   // the commented-out block :383-407 (see the scalar path)
+    f2 cv = splat(0.0f), ca = splat(0.0f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f2 av = (f2){fabsf(vel[k].x), fabsf(vel[k].y)}, aa = (f2){fabsf(acc3[k].x), fabsf(acc3[k].y)};
+      const f2 xv = (av - splat(a.v0)) / splat(a.r_v), xa = (aa - splat(a.a0)) / splat(a.r_a);
+      cv = splat(a.alpha_v) * (f2){expf(xv.x), expf(xv.y)};
+      ca = splat(a.alpha_a) * (f2){expf(xa.x), expf(xa.y)};
+      csum += (cv + ca) * vn * splat(dt);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f2 av = (f2){fabsf(vel[k].x), fabsf(vel[k].y)}, aa = (f2){fabsf(acc3[k].x), fabsf(acc3[k].y)};
+      const f2 xv = (av - splat(a.v0)) / splat(a.r_v), xa = (aa - splat(a.a0)) / splat(a.r_a);
+      const f2 gv = splat(a.alpha_v / a.r_v) * (f2){expf(xv.x), expf(xv.y)};
+      const f2 ga = splat(a.alpha_a / a.r_a) * (f2){expf(xa.x), expf(xa.y)};
+      w2[k] += (gv * vn + cv * (vel[k] * ivn) + ca * (vel[k] * ivn)) * splat(dt);
+      w3[k] = (ga * vn) * splat(dt);
+    }
+    if (!liveA) { csum.x = 0.0f; w2[0].x = w2[1].x = w2[2].x = 0.0f; w3[0].x = w3[1].x = w3[2].x = 0.0f; }
+    if (!liveB) { csum.y = 0.0f; w2[0].y = w2[1].y = w2[2].y = 0.0f; w3[0].y = w3[1].y = w3[2].y = 0.0f; }
+  }
+  const f2 d2 = splat(2.0f) * t, d3 = splat(3.0f) * t2, d4 = splat(4.0f) * t3, d5 = splat(5.0f) * t4;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f2 *ak = acc2 + 6 * k;
+    ak[0] += w1[k];
+    ak[1] += w1[k] * t + w2[k];
+    ak[2] += w1[k] * t2 + w2[k] * d2;
+    ak[3] += w1[k] * t3 + w2[k] * d3;
+    ak[4] += w1[k] * t4 + w2[k] * d4;
+    ak[5] += w1[k] * t5 + w2[k] * d5;
+    if (DYN) {
+      ak[2] += w3[k] * splat(2.0f);
+      ak[3] += w3[k] * splat(6.0f) * t;
+      ak[4] += w3[k] * splat(12.0f) * t2;
+      ak[5] += w3[k] * splat(20.0f) * t3;
+    }
+  }
+  acc2[18] += csum;
+}
+
+// One workgroup owns TPB consecutive trajectories (grid-stride over groups of
+// TPB), NW = blockDim/64 wavefronts.  Each polynomial segment is sampled by
+// LPS = 30/SPL adjacent lanes, SPL samples per lane (sample index =
+// lane-in-segment + j*LPS, so neighbouring lanes gather neighbouring voxels); a
+// wavefront holds SPW = 64/LPS segments.  The workgroup's segments are
+// numbered S = tl*m + s over its TPB trajectories ("virtual segments"), so the
+// few-lane phases (1, 3, 4) and the reduction serve TPB trajectories per pass.
+//   SPL = 1, NW = 3, TPB = 1 : a 20-control-point trajectory over 3 wavefronts
+//                              (small, latency-bound batches)
+//   SPL = 3, NW = 1, TPB = 1 : one wavefront per trajectory (60/64 lanes)
+//   SPL = 15, NW = 1, TPB = 5: 2 lanes per segment, 5 trajectories per wavefront
 template <typename R, bool DYN, int SPL>
 __global__ void __launch_bounds__(512) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a) {
@@ -155,55 +321,79 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *sm = reinterpret_cast<R *>(smem_raw);
   const int m = a.m, ND = 3 * m + 3, ndp = 3 * m - 3, n = 3 * ndp;
+  const int TPB = a.tpb, MS = TPB * m;       // trajectories / virtual segments per workgroup
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, NW = nthr >> 6;
   const int slot = lane / LPS, li = lane - slot * LPS;   // segment slot in this wave, lane in segment
 
-  R *dv = sm;              // [3][ND]   d = [Df | dp] per axis (:302-323)
-  R *Ts = dv + 3 * ND;     // [m]       segment_time
-  R *coef = Ts + m;        // [m][3][6] polynomial coefficients (:253-279)
-  R *Gs = coef + 18 * m;   // [m][3][6] coefficient-space gradient
-  R *csm = Gs + 18 * m;    // [m][3]    jerk cost per (segment, axis)
-  R *ccol = csm + 3 * m;   // [m]       wc * collision (+dyn) cost per segment
-  R *gseg = ccol + m;      // [m][3][6] derivative-space gradient per segment
-  R *tt = gseg + 18 * m;   // [m][30]   sample times (:353)
-  R *dts = tt + kSamples * m;  // [m]   T_s / 30 (:351)
-  R *red = dts + m;        // [NW][kRedChunk][65] per-wave transpose-reduction tile
+  R *dv = sm;                // [TPB][3][ND] d = [Df | dp] per axis (:302-323)
+  R *Ts = dv + 3 * ND * TPB; // [MS]       segment_time
+  R *coef = Ts + MS;         // [MS][3][6] polynomial coefficients (:253-279)
+  R *Gs = coef + 18 * MS;    // [MS][3][6] coefficient-space gradient
+  R *csm = Gs + 18 * MS;     // [MS][3]    jerk cost per (segment, axis)
+  R *ccol = csm + 3 * MS;    // [MS]       wc * collision (+dyn) cost per segment
+  R *gseg = ccol + MS;       // [MS][3][6] derivative-space gradient per segment
+  R *tt = gseg + 18 * MS;    // [MS][30]   sample times (:353)
+  R *dts = tt + kSamples * MS;  // [MS]    T_s / 30 (:351)
+  R *red = dts + MS;         // [NW][kRedChunk][65] per-wave transpose-reduction tile
   R *myred = red + wave * (kRedChunk * kRedStride);
 
   const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
   const R wc = a.wc;
   const bool do_colli = !(gabs(wc) < (R)1e-4);  // :346
 
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    // ---- phase 0: stage this trajectory's x, Df, T in LDS ----
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blocks b
+  // and b+8 share an L2), so give XCD x the x-th contiguous eighth of the
+  // batch: with a spatially ordered batch each L2 then serves one region of
+  // the distance field.  Pure speed; any order is correct.
+  const int ngroups = (a.B + TPB - 1) / TPB;
+  const int per_xcd = (ngroups + 7) >> 3;
+  for (int vb = blockIdx.x; vb < 8 * per_xcd; vb += gridDim.x) {
+    const int grp = (vb & 7) * per_xcd + (vb >> 3);
+    if (grp >= ngroups) continue;      // block-uniform
+    const int b0 = grp * TPB;
+    const int ntraj = min(TPB, a.B - b0);   // trajectories this pass
+    const int nseg = ntraj * m;             // live virtual segments
+    // ---- phase 0: stage x, Df, T of the ntraj trajectories in LDS (contiguous in HBM) ----
     {
-      const R *xb = a.x + (size_t)b * n;
-      for (int i = tid; i < n; i += nthr) {
+      const R *xb = a.x + (size_t)b0 * n;
+      for (int q = tid; q < ntraj * n; q += nthr) {
+        int tl = 0, i = q;
+        while (i >= n) { i -= n; ++tl; }     // TPB is small
         const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
-        dv[axis * ND + 6 + c] = xb[i];
+        dv[(tl * 3 + axis) * ND + 6 + c] = xb[q];
       }
-      const R *dfb = a.Df + (size_t)b * 18;
-      if (tid < 18) {
-        const int axis = tid / 6, j = tid - axis * 6;
-        dv[axis * ND + j] = dfb[tid];
+      const R *dfb = a.Df + (size_t)b0 * 18;
+      for (int q = tid; q < ntraj * 18; q += nthr) {
+        const int tl = q / 18, r = q - tl * 18, axis = r / 6, j = r - axis * 6;
+        dv[(tl * 3 + axis) * ND + j] = dfb[q];
       }
-      const R *tb = a.T + (size_t)b * a.t_stride;
-      for (int i = tid; i < m; i += nthr) Ts[i] = tb[i];
+      if (a.t_stride) {
+        const R *tb = a.T + (size_t)b0 * m;
+        for (int q = tid; q < nseg; q += nthr) Ts[q] = tb[q];
+      } else {
+        for (int q = tid; q < nseg; q += nthr) {
+          int s = q;
+          while (s >= m) s -= m;
+          Ts[q] = a.T[s];
+        }
+      }
     }
     __syncthreads();
 
     // ---- phase 1: per (segment, axis): coefficients, jerk cost, 2Qc ----
-    for (int w = tid; w < 3 * m; w += nthr) {
-      const int s = w / 3, k = w - 3 * s;
-      const R *d = dv + k * ND;
+    for (int w = tid; w < 3 * nseg; w += nthr) {
+      const int S = w / 3, k = w - 3 * S;
+      int tl = 0, s = S;
+      while (s >= m) { s -= m; ++tl; }
+      const R *d = dv + (tl * 3 + k) * ND;
       // global derivative vector layout (src/qp_generator.cpp:363-387):
       // [start p,v,a | end p,v,a | waypoint 1 p,v,a | ... | waypoint m-1 p,v,a]
       const int o0 = (s == 0) ? 0 : 6 + 3 * (s - 1);
       const int o1 = (s + 1 == m) ? 3 : 6 + 3 * s;
       const R p0 = d[o0], v0 = d[o0 + 1], a0 = d[o0 + 2];
       const R pT = d[o1], vT = d[o1 + 1], aT = d[o1 + 2];
-      const R T = Ts[s], T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+      const R T = Ts[S], T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
       const R iT = (R)1 / T, iT3 = iT * iT * iT;
       // closed-form A_s^-1 (rows of A_s: src/qp_generator.cpp:185-195)
       const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
@@ -212,39 +402,39 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
       const R c3 = ((R)10 * P - (R)4 * V + (R)0.5 * A) * iT3;
       const R c4 = ((R)-15 * P + (R)7 * V - A) * (iT3 * iT);
       const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) * (iT3 * iT * iT);
-      R *cf = coef + s * 18 + k * 6;
+      R *cf = coef + w * 6;
       cf[0] = p0; cf[1] = v0; cf[2] = (R)0.5 * a0; cf[3] = c3; cf[4] = c4; cf[5] = c5;
       // jerk Hessian Q_s (src/qp_generator.cpp:226-234): i,j in {3,4,5}
       const R q3 = (R)36 * T * c3 + (R)72 * T2 * c4 + (R)120 * T3 * c5;
       const R q4 = (R)72 * T2 * c3 + (R)192 * T3 * c4 + (R)360 * T4 * c5;
       const R q5 = (R)120 * T3 * c3 + (R)360 * T4 * c4 + (R)720 * T5 * c5;
       csm[w] = c3 * q3 + c4 * q4 + c5 * q5;   // c'Qc  == this (s,k)'s share of d'Rd (:326-327)
-      R *g = Gs + s * 18 + k * 6;             // ws * 2Qc == share of ws*(2Rfp'df + 2Rpp dp) (:330-336)
+      R *g = Gs + w * 6;                      // ws * 2Qc == share of ws*(2Rfp'df + 2Rpp dp) (:330-336)
       g[0] = (R)0; g[1] = (R)0; g[2] = (R)0;
       g[3] = ws * (R)2 * q3; g[4] = ws * (R)2 * q4; g[5] = ws * (R)2 * q5;
     }
     // sample times: `for (t = 1e-3; t < T; t += dt)` (:353) accumulates t by
     // repeated addition, so one lane per segment replays exactly that.
-    for (int s = (int)nthr - 1 - tid; s < m; s += nthr) {   // highest lanes: the ones idle above
-      const R dt = Ts[s] / (R)30.0;             // :351
-      dts[s] = dt;
+    for (int S = (int)nthr - 1 - tid; S < nseg; S += nthr) {   // highest lanes: the ones idle above
+      const R dt = Ts[S] / (R)30.0;             // :351
+      dts[S] = dt;
       R t = (R)1e-3;
-      R *row = tt + s * kSamples;
+      R *row = tt + S * kSamples;
 #pragma unroll 6
       for (int i = 0; i < kSamples; ++i) {
         row[i] = t;
         t += dt;
       }
-      ccol[s] = (R)0;
+      ccol[S] = (R)0;
     }
     __syncthreads();
 
     // ---- phase 2: collision samples (:345-409) ----
     if (do_colli) {
-      for (int s0 = 0; s0 < m; s0 += SPW * NW) {   // block-uniform trip count
-        const int s = s0 + wave * SPW + slot;
-        const bool seg_ok = (slot < SPW) & (s < m);
-        const int sc = seg_ok ? s : 0;             // clamped: inactive lanes compute on segment 0, then discard
+      for (int s0 = 0; s0 < nseg; s0 += SPW * NW) {   // block-uniform trip count
+        const int S = s0 + wave * SPW + slot;
+        const bool seg_ok = (slot < SPW) & (S < nseg);
+        const int sc = seg_ok ? S : 0;             // clamped: inactive lanes compute on segment 0, then discard
         R acc[kRedVals];
 #pragma unroll
         for (int v = 0; v < kRedVals; ++v) acc[v] = (R)0;
@@ -252,6 +442,24 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
         const R dt = dts[sc];
         const R wdt = wc * dt;
         int coff = sc * 18;
+        if constexpr (kIsF32<R> && (SPL % 2 == 0)) {
+          // packed fp32: samples jj and jj+1 of this lane together
+          f2 acc2[kRedVals];
+#pragma unroll
+          for (int v = 0; v < kRedVals; ++v) acc2[v] = (f2){0.0f, 0.0f};
+#pragma unroll GTOP_SAMPLE_UNROLL
+          for (int jj = 0; jj < SPL; jj += 2) {
+            asm volatile("" : "+v"(coff));
+            const float *cq = reinterpret_cast<const float *>(coef) + coff;
+            const float *trow = reinterpret_cast<const float *>(tt) + sc * kSamples + li + jj * LPS;
+            const f2 t = {trow[0], trow[LPS]};
+            const bool liveA = seg_ok & (t.x < (float)Tseg), liveB = seg_ok & (t.y < (float)Tseg);
+            sample_pair_f32<DYN>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, t, liveA, liveB,
+                                 (float)wdt, (float)dt, acc2);
+          }
+#pragma unroll
+          for (int v = 0; v < kRedVals; ++v) acc[v] = (R)(acc2[v].x + acc2[v].y);
+        } else
 #pragma unroll GTOP_SAMPLE_UNROLL
         for (int jj = 0; jj < SPL; ++jj) {
           // the 18 coefficients are re-read from LDS for every sample (broadcast
@@ -335,37 +543,47 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
           }
           acc[18] += csum;
         }
-        // transpose-reduce over the LPS lanes of each segment through LDS, kRedChunk
-        // of the 19 values at a time (keeps the tile at kRedChunk x 65 elements)
+        if (LPS == 1) {
+          // one lane owns the whole segment: no cross-lane reduction
+          if (seg_ok) {
 #pragma unroll
-        for (int c0 = 0; c0 < kRedVals; c0 += kRedChunk) {
-          const int cn = (kRedVals - c0) < kRedChunk ? (kRedVals - c0) : kRedChunk;
-#pragma unroll
-          for (int v = 0; v < kRedChunk; ++v)
-            if (v < cn) myred[v * kRedStride + lane] = acc[c0 + v];
-          __syncthreads();
-          for (int r = lane; r < SPW * cn; r += 64) {
-            const int rs = r / cn, v = r - rs * cn;   // (segment slot, value in chunk)
-            const int sr = s0 + wave * SPW + rs;
-            if (sr < m) {
-              const R *col = myred + v * kRedStride + rs * LPS;
-              R sum = (R)0;
-#pragma unroll
-              for (int i = 0; i < LPS; ++i) sum += col[i];
-              if (c0 + v < 18) Gs[sr * 18 + c0 + v] += sum;
-              else ccol[sr] = sum;
-            }
+            for (int v = 0; v < 18; ++v) Gs[S * 18 + v] += acc[v];
+            ccol[S] = acc[18];
           }
-          __syncthreads();
+        } else {
+          // transpose-reduce over the LPS lanes of each segment through LDS, kRedChunk
+          // of the 19 values at a time (tile = kRedChunk x 65 elements)
+#pragma unroll
+          for (int c0 = 0; c0 < kRedVals; c0 += kRedChunk) {
+            const int cn = (kRedVals - c0) < kRedChunk ? (kRedVals - c0) : kRedChunk;
+#pragma unroll
+            for (int v = 0; v < kRedChunk; ++v)
+              if (v < cn) myred[v * kRedStride + lane] = acc[c0 + v];
+            __syncthreads();
+            for (int r = lane; r < SPW * cn; r += 64) {
+              const int rs = r / cn, v = r - rs * cn;   // (segment slot, value in chunk)
+              const int Sr = s0 + wave * SPW + rs;
+              if (Sr < nseg) {
+                const R *col = myred + v * kRedStride + rs * LPS;
+                R sum = (R)0;
+#pragma unroll
+                for (int i = 0; i < LPS; ++i) sum += col[i];
+                if (c0 + v < 18) Gs[Sr * 18 + c0 + v] += sum;
+                else ccol[Sr] = sum;
+              }
+            }
+            __syncthreads();
+          }
         }
       }
     }
+    if (LPS == 1) __syncthreads();
 
     // ---- phase 3: coefficient space -> derivative space (A_s^-T) ----
-    for (int w = tid; w < 3 * m; w += nthr) {
-      const int s = w / 3;
+    for (int w = tid; w < 3 * nseg; w += nthr) {
+      const int S = w / 3;
       const R *g = Gs + w * 6;
-      const R T = Ts[s], T2 = T * T;
+      const R T = Ts[S], T2 = T * T;
       const R iT = (R)1 / T, iT3 = iT * iT * iT;
       const R H3 = g[3] * iT3, H4 = g[4] * (iT3 * iT), H5 = g[5] * (iT3 * iT * iT);
       const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
@@ -381,31 +599,34 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
 
     // ---- phase 4: gather to the free variables, +1e-5 (:425-432); cost (:417-418) ----
     {
-      R *gb = a.grad + (size_t)b * n;
-      for (int i = tid; i < n; i += nthr) {
+      R *gb = a.grad + (size_t)b0 * n;
+      for (int q = tid; q < ntraj * n; q += nthr) {
+        int tl = 0, i = q;
+        while (i >= n) { i -= n; ++tl; }
         const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
         const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
-        const R v = gseg[((wpt - 1) * 3 + axis) * 6 + 2 * der + 1] +   // end of segment wpt-1
-                    gseg[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
-        gb[i] = v + (R)1e-5;
+        const R *gs = gseg + tl * m * 18;
+        const R v = gs[((wpt - 1) * 3 + axis) * 6 + 2 * der + 1] +   // end of segment wpt-1
+                    gs[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
+        gb[q] = v + (R)1e-5;
       }
-      if (wave == 0) {
+      for (int tl = wave; tl < ntraj; tl += NW) {   // one wavefront shuffle reduction per trajectory
         R part = (R)0;
-        for (int i = lane; i < 3 * m; i += 64) part += ws * csm[i];
-        for (int i = lane; i < m; i += 64) part += ccol[i];
+        for (int i = lane; i < 3 * m; i += 64) part += ws * csm[tl * 3 * m + i];
+        for (int i = lane; i < m; i += 64) part += ccol[tl * m + i];
         part = wave_sum(part);
-        if (lane == 0) a.cost[b] = part + (R)1e-3;
+        if (lane == 0) a.cost[b0 + tl] = part + (R)1e-3;
       }
     }
-    __syncthreads();   // LDS is reused by the next trajectory of this block
+    __syncthreads();   // LDS is reused by the next group of this block
   }
 }
 
 }  // namespace
 
-size_t gtop_eval_smem_bytes(int m, int waves, size_t elem) {
-  const size_t ND = 3 * (size_t)m + 3;
-  size_t elems = 3 * ND + m + 18 * (size_t)m * 3 + 3 * (size_t)m + m + (size_t)kSamples * m + m +
+size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem) {
+  const size_t ND = 3 * (size_t)m + 3, MS = (size_t)tpb * m;
+  size_t elems = 3 * ND * tpb + MS + 18 * MS * 3 + 3 * MS + MS + (size_t)kSamples * MS + MS +
                  (size_t)waves * kRedChunk * kRedStride;
   return elems * elem;
 }
@@ -422,6 +643,9 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, int waves, int spl, 
     case 3: kern = gtop_eval_kernel<R, DYN, 3>; break;
     case 5: kern = gtop_eval_kernel<R, DYN, 5>; break;
     case 6: kern = gtop_eval_kernel<R, DYN, 6>; break;
+    case 10: kern = gtop_eval_kernel<R, DYN, 10>; break;
+    case 15: kern = gtop_eval_kernel<R, DYN, 15>; break;
+    case 30: kern = gtop_eval_kernel<R, DYN, 30>; break;
     default: return hipErrorInvalidValue;
   }
   if (smem > 64 * 1024) {
@@ -437,8 +661,10 @@ template <typename R>
 hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
                             int max_blocks, hipStream_t stream) {
   if (args.B <= 0) return hipSuccess;
-  const size_t smem = gtop_eval_smem_bytes(args.m, waves, sizeof(R));
-  const int grid = args.B < max_blocks ? args.B : max_blocks;
+  const size_t smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, sizeof(R));
+  const int groups = (args.B + args.tpb - 1) / args.tpb;
+  const int vblocks = 8 * ((groups + 7) / 8);   // the kernel walks 8 XCD-contiguous ranges
+  const int grid = vblocks < max_blocks ? vblocks : max_blocks;
   return dyn ? launch_spl<R, true>(args, waves, spl, grid, smem, stream)
              : launch_spl<R, false>(args, waves, spl, grid, smem, stream);
 }

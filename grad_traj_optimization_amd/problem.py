@@ -126,6 +126,24 @@ def make_trajectories(B, m, mapspec, seed=1, step_len=(1.0, 2.0), margin=1.0, no
     return Batch(wp, T, Df, x, m)
 
 
+def spatial_order(waypoints, origin, map_size, bits=7):
+    """Permutation that orders trajectories along a Morton (Z-order) curve of
+    their centroids.  Trajectories that run together on an XCD then read the
+    same region of the distance field (L2 locality); results are unchanged."""
+    wp = np.asarray(waypoints, dtype=np.float64)
+    c = wp.mean(axis=1)
+    q = np.clip(((c - origin) / map_size * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+    code = np.zeros(len(c), dtype=np.int64)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return np.argsort(code, kind="stable")
+
+
+def permute(batch, perm):
+    return Batch(batch.waypoints[perm], batch.T[perm], batch.Df[perm], batch.x[perm], batch.m)
+
+
 def shard_range(B, rank, world_size):
     """Contiguous slice of the batch owned by `rank`."""
     per = (B + world_size - 1) // world_size

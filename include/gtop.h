@@ -182,10 +182,11 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
 
 /* ---- tuning knobs (not in the reference) ---------------------------- */
 
-/* Launch geometry of the evaluation kernel: wavefronts per trajectory
- * workgroup (1..8) and samples per lane (1, 2, 3, 5 or 6: a wavefront then
- * holds 2, 4, 6, 10 or 12 segments).  0 = choose from B and m.  Results do
- * not depend on it beyond fp summation order. */
+/* Launch geometry of the evaluation kernel: wavefronts per workgroup (1..8)
+ * and samples per lane (a divisor of 30: a wavefront then holds 2, 4, 6, 10,
+ * 12, 21, 32 or 64 segments, and a workgroup as many whole trajectories as
+ * fit).  0 = choose from B and m.  Results do not depend on it beyond fp
+ * summation order. */
 int gtop_set_launch_geometry(gtop_ctx *ctx, int waves, int samples_per_lane);
 
 #ifdef __cplusplus

@@ -50,12 +50,12 @@ def test_fp64_parity_host_api(scene, oracle_mod, m, kw):
 
 
 @pytest.mark.parametrize("m", [2, 6, 12, 13])
-@pytest.mark.parametrize("spl", [1, 2, 3, 5, 6])
+@pytest.mark.parametrize("spl", [1, 2, 3, 5, 6, 10, 15, 30])
 @pytest.mark.parametrize("waves", [0, 1, 4])
 def test_fp64_parity_every_launch_geometry(scene, oracle_mod, m, spl, waves):
     """Samples per lane / waves per block only change the work split."""
     mp, ctx, sdf = scene
-    b = problem.make_trajectories(16, m, mp, seed=200 + m)
+    b = problem.make_trajectories(23, m, mp, seed=200 + m)   # odd: exercises a partial last workgroup
     kw = dict(ws=0.0)          # collision term alone: the part the geometry touches
     ctx.set_launch_geometry(waves, spl)
     ctx.set_params(**kw)
