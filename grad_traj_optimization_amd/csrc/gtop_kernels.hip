@@ -56,6 +56,43 @@ template <> constexpr bool kIsF32<float> = true;
 template <typename R> __device__ __forceinline__ R gexp(R v);
 template <> __device__ __forceinline__ double gexp<double>(double v) { return exp(v); }
 template <> __device__ __forceinline__ float gexp<float>(float v) { return expf(v); }
+
+// exp for the per-sample penalty (src/grad_traj_optimizer.cpp:509,:514): one
+// range reduction x = k ln2 + r, |r| <= ln2/2, a degree-13 Taylor/Horner
+// polynomial (truncation 4e-18 relative) and ldexp: < 2 ulp, about half the
+// instructions of the library routine.  Huge |x| saturate to 0 / inf through
+// v_ldexp_f64; NaN propagates.
+__device__ __forceinline__ double penalty_exp(double x) {
+  const double k = rint(x * 1.4426950408889634074);            // x / ln2
+  double r = fma(k, -6.93147180369123816490e-01, x);            // ln2 hi
+  r = fma(k, -1.90821492927058770002e-10, r);                   // ln2 lo
+  double p = 1.6059043836821613e-10;                            // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);                          // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);                         // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);                         // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);                        // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);                          // 1/8!
+  p = fma(p, r, 1.984126984126984e-04);                         // 1/7!
+  p = fma(p, r, 1.388888888888889e-03);                         // 1/6!
+  p = fma(p, r, 8.333333333333333e-03);                         // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);                        // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);                        // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double kc = fmin(fmax(k, -2100.0), 2100.0);             // keep the int conversion defined
+  return ldexp(p, (int)kc);
+}
+__device__ __forceinline__ float penalty_exp(float x) { return expf(x); }
+
+// 1/x: hardware estimate + two Newton steps (fp64), full-precision divide (fp32)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 template <typename R> __device__ __forceinline__ R gsqrt(R v);
 template <> __device__ __forceinline__ double gsqrt<double>(double v) { return sqrt(v); }
 template <> __device__ __forceinline__ float gsqrt<float>(float v) { return sqrtf(v); }
@@ -78,7 +115,7 @@ __device__ __forceinline__ float round_through_float(float v) { return v; }
 // are always in bounds and the out-of-map case is a final select.
 template <typename R>
 __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R pz,
-                                       R &gx, R &gy, R &gz) {
+                                       R &gx, R &gy, R &gz, bool &is_out) {
   const bool out = (px < a.lo[0]) | (py < a.lo[1]) | (pz < a.lo[2]) |
                    (px > a.hi[0]) | (py > a.hi[1]) | (pz > a.hi[2]);
   const R res = a.res, rinv = a.res_inv;
@@ -107,31 +144,32 @@ __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R
   const Pair<R> p01 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y1) * nz + zb));
   const Pair<R> p10 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y0) * nz + zb));
   const Pair<R> p11 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y1) * nz + zb));
-  // values[x][y][z]
-  const R v000 = z_hi ? p00.y : p00.x, v001 = z_lo ? p00.x : p00.y;
-  const R v010 = z_hi ? p01.y : p01.x, v011 = z_lo ? p01.x : p01.y;
-  const R v100 = z_hi ? p10.y : p10.x, v101 = z_lo ? p10.x : p10.y;
-  const R v110 = z_hi ? p11.y : p11.x, v111 = z_lo ? p11.x : p11.y;
+  // values[x][y][z].  At a z border both z-corners clamp to the same voxel
+  // (:166-174); with the pair (D[zb], D[zb+1]) in hand that is dz := 0
+  // (iz = -1) or dz := 1 (iz = nz-1) and a zero z-gradient.
+  const R dze = z_lo ? (R)0 : (z_hi ? (R)1 : dz);
+  const R v000 = p00.x, v001 = p00.y, v010 = p01.x, v011 = p01.y;
+  const R v100 = p10.x, v101 = p10.y, v110 = p11.x, v111 = p11.y;
 
   const R one = (R)1;
-  const R ex = one - dx, ey = one - dy, ez = one - dz;
+  const R ex = one - dx, ey = one - dy, ez = one - dze;
   const R v00 = ex * v000 + dx * v100;  // :221-224
   const R v01 = ex * v001 + dx * v101;
   const R v10 = ex * v010 + dx * v110;
   const R v11 = ex * v011 + dx * v111;
   const R v0 = ey * v00 + dy * v10;     // :226-227
   const R v1 = ey * v01 + dy * v11;
-  const R dist = ez * v0 + dz * v1;     // :229
+  const R dist = ez * v0 + dze * v1;    // :229
   const R gzz = (v1 - v0) * rinv;       // :231
-  const R gyy = (ez * (v10 - v00) + dz * (v11 - v01)) * rinv;  // :232-233
+  gy = (ez * (v10 - v00) + dze * (v11 - v01)) * rinv;  // :232-233
   R g0 = ez * ey * (v100 - v000);       // :234-239
   g0 += ez * dy * (v110 - v010);
-  g0 += dz * ey * (v101 - v001);
-  g0 += dz * dy * (v111 - v011);
-  gx = out ? (R)0 : g0 * rinv;
-  gy = out ? (R)0 : gyy;
-  gz = out ? (R)0 : gzz;
-  return out ? (R)-1 : dist;
+  g0 += dze * ey * (v101 - v001);
+  g0 += dze * dy * (v111 - v011);
+  gx = g0 * rinv;
+  gz = (z_lo | z_hi) ? (R)0 : gzz;
+  is_out = out;
+  return out ? (R)-1 : dist;   // the caller zeroes the gradient's weight when out (grad := 0)
 }
 
 template <typename R>
@@ -481,17 +519,18 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
               acc3[k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
           }
           const R vn = gsqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;  // :358
-          const R ivn = (R)1 / vn;
+          const R ivn = fast_rcp(vn);
           R g3[3];
-          const R dist = sdf_query(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2]);  // :363
+          bool is_out;
+          const R dist = sdf_query(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2], is_out);  // :363
           // samples past the loop bound of :353 and idle lanes contribute nothing:
           // every term below carries a factor e
-          const R e = live ? gexp((a.d0 - dist) * a.inv_r) : (R)0;   // exp(-(d - d0)/r)
+          const R e = live ? penalty_exp((a.d0 - dist) * a.inv_r) : (R)0;   // exp(-(d - d0)/r)
           const R cd = a.alpha * e;                    // :509
           const R gd = -a.alpha_over_r * e;            // :514
           R csum = wdt * (cd * vn);                    // :373, weighted as in :417-418
           // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
-          const R f1 = wdt * (gd * cd * vn), f2 = wdt * (cd * ivn);
+          const R f1 = is_out ? (R)0 : wdt * (gd * cd * vn), f2 = wdt * (cd * ivn);
           R w1[3], w2[3], w3[3];
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
