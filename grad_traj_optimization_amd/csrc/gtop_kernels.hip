@@ -49,6 +49,23 @@ constexpr int kRedStride = 65;   // 64 lanes + 1 pad: conflict-free column reads
 #endif
 constexpr int kRedChunk = GTOP_RED_CHUNK;   // values per transpose-reduction pass
 
+// Diagnostic build (-DGTOP_STAMPS): s_memtime at the phase boundaries of lane 0
+// of wave 0 of the first 4096 workgroups, into a buffer of its own that nothing
+// else reads.  Never defined in the shipped library.
+#ifdef GTOP_STAMPS
+__device__ unsigned long long g_gtop_stamps[4096][8];
+#define GTOP_STAMP(i)                                                                          \
+  do {                                                                                         \
+    unsigned long long t_;                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtop_stamps[blockIdx.x][i] = t_;              \
+  } while (0)
+#else
+#define GTOP_STAMP(i)
+#endif
+
 template <typename R> struct Pair { R x, y; } __attribute__((packed));
 template <typename R> constexpr bool kIsF32 = false;
 template <> constexpr bool kIsF32<float> = true;
@@ -172,11 +189,46 @@ __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R
   return out ? (R)-1 : dist;   // the caller zeroes the gradient's weight when out (grad := 0)
 }
 
+// Wavefront sum on the DPP cross-lane path (no LDS round trips): quad swaps,
+// row shifts, then the two row broadcasts; every lane's contribution ends up in
+// lane 63, which is read back with readlane.  __shfl_xor would go through
+// ds_bpermute (~100+ cycles per step); this is ~10.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_move(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <typename R>
 __device__ __forceinline__ R wave_sum(R v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move<0xb1>(v);         // quad_perm [1,0,3,2]
+  v += dpp_move<0x4e>(v);         // quad_perm [2,3,0,1]
+  v += dpp_move<0x114>(v);        // row_shr:4
+  v += dpp_move<0x118>(v);        // row_shr:8   -> lane 15 of each row holds the row sum
+  v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  if constexpr (sizeof(R) == 8) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+    return __builtin_bit_cast(R, ((unsigned long long)hi << 32) | lo);
+  } else {
+    return __builtin_bit_cast(R, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  }
+}
+
+// sum of N consecutive values as a balanced tree (depth log2 N instead of an
+// N-long dependent chain)
+template <typename R, int N>
+__device__ __forceinline__ R tree_sum(const R *p) {
+  if constexpr (N == 1) return p[0];
+  else if constexpr (N == 2) return p[0] + p[1];
+  else return tree_sum<R, N / 2>(p) + tree_sum<R, N - N / 2>(p + N / 2);
 }
 
 // ---------------------------------------------------------------------------
@@ -370,10 +422,10 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
   R *Gs = coef + 18 * MS;    // [MS][3][6] coefficient-space gradient
   R *csm = Gs + 18 * MS;     // [MS][3]    jerk cost per (segment, axis)
   R *ccol = csm + 3 * MS;    // [MS]       wc * collision (+dyn) cost per segment
-  R *gseg = ccol + MS;       // [MS][3][6] derivative-space gradient per segment
-  R *tt = gseg + 18 * MS;    // [MS][30]   sample times (:353)
-  R *dts = tt + kSamples * MS;  // [MS]    T_s / 30 (:351)
-  R *red = dts + MS;         // [NW][kRedChunk][65] per-wave transpose-reduction tile
+  R *gseg = coef;            // [MS][3][6] derivative-space gradient per segment (phase 3 on; coef is dead by then)
+  R *dts = ccol + MS;        // [MS]       T_s / 30 (:351)
+  R *Gc = dts + MS;          // [MS][3][6] wc * collision gradient, coefficient space
+  R *red = Gc + 18 * MS;     // [NW][kRedChunk][65] per-wave transpose-reduction tile
   R *myred = red + wave * (kRedChunk * kRedStride);
 
   const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
@@ -390,6 +442,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
     const int grp = (vb & 7) * per_xcd + (vb >> 3);
     if (grp >= ngroups) continue;      // block-uniform
     const int b0 = grp * TPB;
+    GTOP_STAMP(0);
     const int ntraj = min(TPB, a.B - b0);   // trajectories this pass
     const int nseg = ntraj * m;             // live virtual segments
     // ---- phase 0: stage x, Df, T of the ntraj trajectories in LDS (contiguous in HBM) ----
@@ -418,6 +471,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
       }
     }
     __syncthreads();
+    GTOP_STAMP(1);
 
     // ---- phase 1: per (segment, axis): coefficients, jerk cost, 2Qc ----
     for (int w = tid; w < 3 * nseg; w += nthr) {
@@ -432,7 +486,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
       const R p0 = d[o0], v0 = d[o0 + 1], a0 = d[o0 + 2];
       const R pT = d[o1], vT = d[o1 + 1], aT = d[o1 + 2];
       const R T = Ts[S], T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
-      const R iT = (R)1 / T, iT3 = iT * iT * iT;
+      const R iT = fast_rcp(T), iT3 = iT * iT * iT;
       // closed-form A_s^-1 (rows of A_s: src/qp_generator.cpp:185-195)
       const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
       const R V = (vT - v0 - a0 * T) * T;
@@ -451,21 +505,21 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
       g[0] = (R)0; g[1] = (R)0; g[2] = (R)0;
       g[3] = ws * (R)2 * q3; g[4] = ws * (R)2 * q4; g[5] = ws * (R)2 * q5;
     }
-    // sample times: `for (t = 1e-3; t < T; t += dt)` (:353) accumulates t by
-    // repeated addition, so one lane per segment replays exactly that.
+    // sample times.  The reference's `for (t = 1e-3; t < T; t += dt)` (:353)
+    // accumulates t by repeated addition.  For T >= 0.0301 all 30 samples pass
+    // the loop test whatever the rounding, and t_i = 1e-3 + i*dt differs from the
+    // accumulated value by a few ulp (1e-15 relative, far inside the 1e-5
+    // budget), so lanes form it with one fma.  Below that the
+    // sample COUNT depends on the accumulated value (29 at T = 0.03, fewer for
+    // tinier T), so for those segments each lane replays the addition chain.
     for (int S = (int)nthr - 1 - tid; S < nseg; S += nthr) {   // highest lanes: the ones idle above
-      const R dt = Ts[S] / (R)30.0;             // :351
+      const R Tv = Ts[S];
+      const R dt = Tv / (R)30.0;                // :351
       dts[S] = dt;
-      R t = (R)1e-3;
-      R *row = tt + S * kSamples;
-#pragma unroll 6
-      for (int i = 0; i < kSamples; ++i) {
-        row[i] = t;
-        t += dt;
-      }
       ccol[S] = (R)0;
     }
     __syncthreads();
+    GTOP_STAMP(2);
 
     // ---- phase 2: collision samples (:345-409) ----
     if (do_colli) {
@@ -479,6 +533,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
         const R Tseg = Ts[sc];
         const R dt = dts[sc];
         const R wdt = wc * dt;
+        const bool tiny_T = Tseg < (R)0.0301;
         int coff = sc * 18;
         if constexpr (kIsF32<R> && (SPL % 2 == 0)) {
           // packed fp32: samples jj and jj+1 of this lane together
@@ -489,8 +544,15 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
           for (int jj = 0; jj < SPL; jj += 2) {
             asm volatile("" : "+v"(coff));
             const float *cq = reinterpret_cast<const float *>(coef) + coff;
-            const float *trow = reinterpret_cast<const float *>(tt) + sc * kSamples + li + jj * LPS;
-            const f2 t = {trow[0], trow[LPS]};
+            const int si = li + jj * LPS;
+            f2 t = {(float)si * (float)dt + 1e-3f, (float)(si + LPS) * (float)dt + 1e-3f};
+            if (tiny_T) {   // rare: exact replay of `t += dt`
+              float ta = 1e-3f;
+              for (int i = 0; i < si; ++i) ta += (float)dt;
+              float tb = ta;
+              for (int i = 0; i < LPS; ++i) tb += (float)dt;
+              t = (f2){ta, tb};
+            }
             const bool liveA = seg_ok & (t.x < (float)Tseg), liveB = seg_ok & (t.y < (float)Tseg);
             sample_pair_f32<DYN>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, t, liveA, liveB,
                                  (float)wdt, (float)dt, acc2);
@@ -505,7 +567,12 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
           // keeps the compiler from hoisting them back out.
           asm volatile("" : "+v"(coff));
           const R *cq = coef + coff;
-          const R t = tt[sc * kSamples + li + jj * LPS];
+          const int si = li + jj * LPS;                                 // sample index 0..29
+          R t = (R)si * dt + (R)1e-3;
+          if (tiny_T) {   // rare: exact replay of `t += dt`
+            t = (R)1e-3;
+            for (int i = 0; i < si; ++i) t += dt;
+          }
           const bool live = seg_ok & (t < Tseg);   // the loop condition of :353
           const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
           R pos[3], vel[3], acc3[3];
@@ -567,12 +634,21 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             R *ak = acc + 6 * k;
-            ak[0] += w1[k];
-            ak[1] += w1[k] * t + w2[k];
-            ak[2] += w1[k] * t2 + w2[k] * d2;
-            ak[3] += w1[k] * t3 + w2[k] * d3;
-            ak[4] += w1[k] * t4 + w2[k] * d4;
-            ak[5] += w1[k] * t5 + w2[k] * d5;
+            if constexpr (SPL == 1) {   // single sample per lane: assign (saves 19 adds of zero)
+              ak[0] = w1[k];
+              ak[1] = w1[k] * t + w2[k];
+              ak[2] = w1[k] * t2 + w2[k] * d2;
+              ak[3] = w1[k] * t3 + w2[k] * d3;
+              ak[4] = w1[k] * t4 + w2[k] * d4;
+              ak[5] = w1[k] * t5 + w2[k] * d5;
+            } else {
+              ak[0] += w1[k];
+              ak[1] += w1[k] * t + w2[k];
+              ak[2] += w1[k] * t2 + w2[k] * d2;
+              ak[3] += w1[k] * t3 + w2[k] * d3;
+              ak[4] += w1[k] * t4 + w2[k] * d4;
+              ak[5] += w1[k] * t5 + w2[k] * d5;
+            }
             if (DYN) {
               ak[2] += w3[k] * (R)2;
               ak[3] += w3[k] * (R)6 * t;
@@ -580,13 +656,18 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
               ak[5] += w3[k] * (R)20 * t3;
             }
           }
-          acc[18] += csum;
+          if constexpr (SPL == 1) acc[18] = csum;
+          else acc[18] += csum;
         }
+#ifdef GTOP_STAMPS   // pin the sample arithmetic in front of the stamp
+        asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[11]), "v"(acc[17]), "v"(acc[18]));
+#endif
+        GTOP_STAMP(3);
         if (LPS == 1) {
           // one lane owns the whole segment: no cross-lane reduction
           if (seg_ok) {
 #pragma unroll
-            for (int v = 0; v < 18; ++v) Gs[S * 18 + v] += acc[v];
+            for (int v = 0; v < 18; ++v) Gc[S * 18 + v] = acc[v];
             ccol[S] = acc[18];
           }
         } else {
@@ -599,31 +680,46 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
             for (int v = 0; v < kRedChunk; ++v)
               if (v < cn) myred[v * kRedStride + lane] = acc[c0 + v];
             __syncthreads();
-            for (int r = lane; r < SPW * cn; r += 64) {
-              const int rs = r / cn, v = r - rs * cn;   // (segment slot, value in chunk)
-              const int Sr = s0 + wave * SPW + rs;
-              if (Sr < nseg) {
-                const R *col = myred + v * kRedStride + rs * LPS;
-                R sum = (R)0;
+            // each lane owns up to kRdr (segment slot, value) sums; all tile reads are
+            // issued before any result is stored (one LDS round trip, not kRdr)
+            constexpr int kRdr = (SPW * kRedChunk + 63) / 64;
+            R sums[kRdr];
 #pragma unroll
-                for (int i = 0; i < LPS; ++i) sum += col[i];
-                if (c0 + v < 18) Gs[Sr * 18 + c0 + v] += sum;
-                else ccol[Sr] = sum;
+            for (int u = 0; u < kRdr; ++u) {
+              const int r = lane + 64 * u;
+              const int rs = r / cn, v = r - rs * cn;   // (segment slot, value in chunk)
+              const bool ok = (r < SPW * cn) & (s0 + wave * SPW + rs < nseg);
+              const R *col = myred + (ok ? v * kRedStride + rs * LPS : 0);
+              sums[u] = tree_sum<R, LPS>(col);
+            }
+#pragma unroll
+            for (int u = 0; u < kRdr; ++u) {
+              const int r = lane + 64 * u;
+              const int rs = r / cn, v = r - rs * cn;
+              const int Sr = s0 + wave * SPW + rs;
+              if ((r < SPW * cn) & (Sr < nseg)) {
+                if (c0 + v < 18) Gc[Sr * 18 + c0 + v] = sums[u];
+                else ccol[Sr] = sums[u];
               }
             }
             __syncthreads();
           }
         }
       }
+    } else {
+      for (int q = tid; q < 18 * nseg; q += nthr) Gc[q] = (R)0;   // |wc| < 1e-4: no collision term (:346)
     }
     if (LPS == 1) __syncthreads();
+    GTOP_STAMP(4);
 
     // ---- phase 3: coefficient space -> derivative space (A_s^-T) ----
     for (int w = tid; w < 3 * nseg; w += nthr) {
       const int S = w / 3;
-      const R *g = Gs + w * 6;
+      R g[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) g[j] = Gs[w * 6 + j] + Gc[w * 6 + j];
       const R T = Ts[S], T2 = T * T;
-      const R iT = (R)1 / T, iT3 = iT * iT * iT;
+      const R iT = fast_rcp(T), iT3 = iT * iT * iT;
       const R H3 = g[3] * iT3, H4 = g[4] * (iT3 * iT), H5 = g[5] * (iT3 * iT * iT);
       const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
       R *o = gseg + w * 6;   // [p0, pT, v0, vT, a0, aT]
@@ -635,6 +731,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
       o[5] = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
     }
     __syncthreads();
+    GTOP_STAMP(5);
 
     // ---- phase 4: gather to the free variables, +1e-5 (:425-432); cost (:417-418) ----
     {
@@ -657,6 +754,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
         if (lane == 0) a.cost[b0 + tl] = part + (R)1e-3;
       }
     }
+    GTOP_STAMP(6);
     __syncthreads();   // LDS is reused by the next group of this block
   }
 }
@@ -665,7 +763,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
 
 size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem) {
   const size_t ND = 3 * (size_t)m + 3, MS = (size_t)tpb * m;
-  size_t elems = 3 * ND * tpb + MS + 18 * MS * 3 + 3 * MS + MS + (size_t)kSamples * MS + MS +
+  size_t elems = 3 * ND * tpb + MS + 18 * MS * 2 + 3 * MS + MS + MS + 18 * MS +
                  (size_t)waves * kRedChunk * kRedStride;
   return elems * elem;
 }
@@ -707,6 +805,12 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, b
   return dyn ? launch_spl<R, true>(args, waves, spl, grid, smem, stream)
              : launch_spl<R, false>(args, waves, spl, grid, smem, stream);
 }
+
+#ifdef GTOP_STAMPS
+extern "C" int gtop_debug_read_stamps(unsigned long long *out /*4096*8*/) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gtop_stamps), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
 
 template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, int, bool, int, hipStream_t);
 template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, int, bool, int, hipStream_t);

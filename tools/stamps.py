@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycles of gtop_eval_kernel from a -DGTOP_STAMPS build.
+usage: GTOP_HIP_LIB=build_var/libS.so python tools/stamps.py [B] [spl] [waves] [dtype]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.getcwd())
+import grad_traj_optimization_amd as gtop
+from grad_traj_optimization_amd import problem
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+spl = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+waves = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+dt = torch.float64 if (len(sys.argv) <= 4 or sys.argv[4] == "f64") else torch.float32
+mp = problem.make_map(200, density=0.02, seed=0)
+ctx = gtop.GtopContext(0)
+ctx.set_launch_geometry(waves, spl)
+ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+ctx.update_sdf_map(mp.obstacle_points())
+b = problem.make_trajectories(B, 6, mp, seed=1)
+dev = torch.device("cuda:0")
+x = torch.tensor(b.x, dtype=dt, device=dev)
+Df = torch.tensor(b.Df.reshape(-1, 18), dtype=dt, device=dev)
+T = torch.tensor(b.T, dtype=dt, device=dev)
+cost, grad = ctx.eval_device(x, Df, T)
+for _ in range(20):
+    ctx.eval_device(x, Df, T, cost, grad)
+torch.cuda.synchronize()
+L = gtop.load_library()
+buf = np.zeros((4096, 8), dtype=np.uint64)
+rc = L.gtop_debug_read_stamps(buf.ctypes.data_as(C.c_void_p))
+assert rc == 0
+nb = min(4096, B)
+s = buf[:nb, :7].astype(np.int64)
+d = np.diff(s, axis=1)
+names = ["phase0 load+stage", "phase1 coeff+ttable", "phase2 samples", "reduction", "phase3 A^-T", "phase4 store+cost"]
+print(f"B={B} spl={spl} waves={waves} dtype={dt}: median cycles per phase (lane 0 of wave 0), first {nb} blocks")
+for i, nme in enumerate(names):
+    print(f"  {nme:22s} median {np.median(d[:, i]):8.0f}   p10 {np.percentile(d[:, i], 10):8.0f}   p90 {np.percentile(d[:, i], 90):8.0f}")
+print(f"  total                  median {np.median(s[:, 6] - s[:, 0]):8.0f}")
+print(f"  first start -> last end: {(s[:, 6].max() - s[:, 0].min())} cycles; block start spread {(s[:, 0].max() - s[:, 0].min())}")
