@@ -35,6 +35,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def measured_traffic(key):
+    """HBM-side bytes per launch of gtop_eval_kernel for this workload, from the
+    rocprofv3 --pmc passes committed under profiles/ (tools/pmc_collect.sh +
+    tools/pmc_summary.py; counters cannot be read from inside this process).
+    None when this workload has not been profiled."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        return t.get(key)
+    except (OSError, ValueError):
+        return None
+
 
 
 def algorithmic_bytes(m, elem):
@@ -236,6 +251,7 @@ def main():
         log(f"timed region done: {elapsed:.4f} s for {args.steps} steps")
         evals = B_total * args.steps
         value = evals / elapsed
+        wkey = f"B{Bl}_m{m}_g{args.grid}_{args.dtype}"
         bpe = algorithmic_bytes(m, elem)
         achieved = (hi - lo) * bpe / (kern_ms * 1e-3) / 1e9    # GB/s, per launch on this rank
         out = {
@@ -259,7 +275,8 @@ def main():
                 "bound": "hbm", "kernel": "gtop_eval_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": (measured_traffic(wkey) or {}).get("traffic_bytes"),
+                "traffic_source": (measured_traffic(wkey) or {}).get("source"),
                 "algorithmic_bytes_per_eval": bpe, "evals_per_launch": hi - lo,
                 "avg_launch_us": kern_ms * 1e3,
             },
