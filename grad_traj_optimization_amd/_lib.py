@@ -91,6 +91,12 @@ def load_library():
         "gtop_eval_batch": (C.c_int, [vp, C.c_int, dp, dp, dp]),
         "gtop_cost_nlopt": (C.c_double, [C.c_uint, dp, dp, vp]),
         "gtop_eval_device": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]),
+        "gtop_set_paths": (C.c_int, [vp, C.c_int, C.c_int, dp, C.c_double, C.c_double, dp]),
+        "gtop_setup_paths_device": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_double, C.c_double, vp, vp, vp, vp]),
+        "gtop_get_problem": (C.c_int, [vp, dp, dp]),
+        "gtop_coefficients_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]),
+        "gtop_eval_trajectories_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp]),
+        "gtop_trajectory_stats": (C.c_int, [vp, C.c_int, dp, C.c_double, dp, dp]),
         "gtop_default_bounds": (C.c_int, [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_double, dp, dp]),
         "gtop_optimize_batch": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, dp]),
         "gtop_optimize_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]),
@@ -250,6 +256,34 @@ class GtopContext:
                                            C.c_void_p(cost.data_ptr()), C.c_void_p(grad.data_ptr()),
                                            C.c_void_p(stream)))
         return cost, grad
+
+    # -- setup / post-processing --
+    TRAJ_STATS = ("time_sum", "length", "jerk", "mean_v", "max_v", "mean_a", "max_a", "acc_cost", "n_samples")
+
+    def set_paths(self, waypoints, mean_v=1.8, init_time=0.3):
+        """setPath for a batch: (B, m+1, 3) waypoints -> the context's problem; returns x0 (B, n)."""
+        wp = _f64(waypoints)
+        B, npts, _ = wp.shape
+        m = npts - 1
+        x0 = np.empty((B, 9 * (m - 1)))
+        self._chk(self._L.gtop_set_paths(self._h, B, m, _p(wp), float(mean_v), float(init_time), _p(x0)))
+        self.B, self.m = B, m
+        return x0
+
+    def get_problem(self):
+        T = np.empty((self.B, self.m))
+        Df = np.empty((self.B, 3, 6))
+        self._chk(self._L.gtop_get_problem(self._h, _p(T), _p(Df)))
+        return T, Df
+
+    def trajectory_stats(self, x, dt_sample=0.01):
+        """(coefficients (B, m, 18), stats (B, 9)) for the context's problem at free variables x."""
+        x = _f64(x)
+        B = x.shape[0]
+        coeff = np.empty((B, self.m, 18))
+        stats = np.empty((B, len(self.TRAJ_STATS)))
+        self._chk(self._L.gtop_trajectory_stats(self._h, B, _p(x), float(dt_sample), _p(coeff), _p(stats)))
+        return coeff, stats
 
     # -- batched optimizer --
     @staticmethod

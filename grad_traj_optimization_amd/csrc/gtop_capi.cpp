@@ -457,6 +457,107 @@ int gtop_eval_device(gtop_ctx *c, int dtype, int B, int m, const void *d_x, cons
   return fail(c, GTOP_ERR_INVALID, "bad dtype");
 }
 
+// ---- setup (f3) and post-processing (f4) ----
+int gtop_setup_paths_device(gtop_ctx *c, int B, int m, const void *d_wp, double mean_v, double init_time,
+                            void *d_T, void *d_Df, void *d_x0, void *hip_stream) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (B < 0 || m < 2 || !(mean_v > 0.0)) return fail(c, GTOP_ERR_INVALID, "setup_paths: need B >= 0, m >= 2, mean_v > 0");
+  if (B == 0) return GTOP_OK;
+  if (!d_wp || !d_T || !d_Df || !d_x0) return fail(c, GTOP_ERR_INVALID, "setup_paths: NULL buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, gtop_launch_setup_paths(B, m, static_cast<const double *>(d_wp), mean_v, init_time,
+                                    static_cast<double *>(d_T), static_cast<double *>(d_Df),
+                                    static_cast<double *>(d_x0), static_cast<hipStream_t>(hip_stream)));
+  return GTOP_OK;
+}
+
+int gtop_set_paths(gtop_ctx *c, int B, int m, const double *waypoints, double mean_v, double init_time,
+                   double *x0) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (B < 1 || m < 2 || !waypoints || !(mean_v > 0.0))
+    return fail(c, GTOP_ERR_INVALID, "set_paths: need B >= 1, m >= 2 (3+ waypoints), mean_v > 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = 9 * (size_t)(m - 1), nwp = (size_t)B * (m + 1) * 3;
+  int rc;
+  if ((rc = ensure(c, &c->d_T, &c->cap_T, (size_t)B * m))) return rc;
+  if ((rc = ensure(c, &c->d_Df, &c->cap_Df, (size_t)B * 18))) return rc;
+  if ((rc = ensure(c, &c->d_x, &c->cap_x, (size_t)B * n))) return rc;
+  if ((rc = ensure(c, &c->d_grad, &c->cap_grad, (size_t)B * n))) return rc;
+  if ((rc = ensure(c, &c->d_cost, &c->cap_cost, (size_t)B))) return rc;
+  if ((rc = ensure(c, &c->d_pts, &c->pts_cap, nwp))) return rc;   // staging, shared with the obstacle list
+  HIPCHK(c, hipMemcpyAsync(c->d_pts, waypoints, nwp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if ((rc = gtop_setup_paths_device(c, B, m, c->d_pts, mean_v, init_time, c->d_T, c->d_Df, c->d_x, c->stream)))
+    return rc;
+  if (x0) HIPCHK(c, hipMemcpyAsync(x0, c->d_x, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->B = B; c->m = m; c->t_stride = m;
+  return GTOP_OK;
+}
+
+int gtop_get_problem(gtop_ctx *c, double *segment_time, double *Df) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (c->B == 0) return fail(c, GTOP_ERR_STATE, "no problem set");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nT = c->t_stride ? (size_t)c->B * c->m : (size_t)c->m;
+  if (segment_time)
+    HIPCHK(c, hipMemcpyAsync(segment_time, c->d_T, nT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (Df) HIPCHK(c, hipMemcpyAsync(Df, c->d_Df, (size_t)c->B * 18 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
+int gtop_coefficients_device(gtop_ctx *c, int B, int m, const void *d_x, const void *d_Df, const void *d_T,
+                             int time_stride, void *d_coeff, void *hip_stream) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (B < 0 || m < 2 || (time_stride != 0 && time_stride != m))
+    return fail(c, GTOP_ERR_INVALID, "coefficients: need B >= 0, m >= 2, time_stride in {0, m}");
+  if (B == 0) return GTOP_OK;
+  if (!d_x || !d_Df || !d_T || !d_coeff) return fail(c, GTOP_ERR_INVALID, "coefficients: NULL buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, gtop_launch_coefficients(B, m, static_cast<const double *>(d_x), static_cast<const double *>(d_Df),
+                                     static_cast<const double *>(d_T), time_stride, static_cast<double *>(d_coeff),
+                                     static_cast<hipStream_t>(hip_stream)));
+  return GTOP_OK;
+}
+
+int gtop_eval_trajectories_device(gtop_ctx *c, int B, int m, const void *d_coeff, const void *d_T, int time_stride,
+                                  double dt_sample, void *d_stats, void *hip_stream) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (B < 0 || m < 1 || !(dt_sample > 0.0) || (time_stride != 0 && time_stride != m))
+    return fail(c, GTOP_ERR_INVALID, "eval_trajectories: need B >= 0, m >= 1, dt_sample > 0, time_stride in {0, m}");
+  if (B == 0) return GTOP_OK;
+  if (!d_coeff || !d_T || !d_stats) return fail(c, GTOP_ERR_INVALID, "eval_trajectories: NULL buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, gtop_launch_eval_trajectories(B, m, static_cast<const double *>(d_coeff), static_cast<const double *>(d_T),
+                                          time_stride, dt_sample, static_cast<double *>(d_stats),
+                                          static_cast<hipStream_t>(hip_stream)));
+  return GTOP_OK;
+}
+
+int gtop_trajectory_stats(gtop_ctx *c, int B, const double *x, double dt_sample, double *coeff, double *stats) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (c->B == 0) return fail(c, GTOP_ERR_STATE, "gtop_set_problem / gtop_set_paths has not been called");
+  if (B < 1 || B > c->B || !x || (!coeff && !stats))
+    return fail(c, GTOP_ERR_INVALID, "trajectory_stats: 1 <= B <= problem batch, x and an output required");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int m = c->m;
+  const size_t n = 9 * (size_t)(m - 1), ncoef = (size_t)B * m * 18;
+  int rc;
+  if ((rc = ensure(c, &c->mma_g, &c->cap_mma_g, ncoef > (size_t)B * n ? ncoef : (size_t)B * n))) return rc;   // coefficient scratch
+  if ((rc = ensure(c, &c->mma_f, &c->cap_mma_f, (size_t)B * GTOP_TRAJ_STATS))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_x, x, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if ((rc = gtop_coefficients_device(c, B, m, c->d_x, c->d_Df, c->d_T, c->t_stride, c->mma_g, c->stream))) return rc;
+  if (coeff) HIPCHK(c, hipMemcpyAsync(coeff, c->mma_g, ncoef * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (stats) {
+    if ((rc = gtop_eval_trajectories_device(c, B, m, c->mma_g, c->d_T, c->t_stride, dt_sample, c->mma_f, c->stream)))
+      return rc;
+    HIPCHK(c, hipMemcpyAsync(stats, c->mma_f, (size_t)B * GTOP_TRAJ_STATS * sizeof(double), hipMemcpyDeviceToHost,
+                             c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
 // Batched optimizer: max_evals lock-step iterations of {cost/gradient kernel,
 // MMA update kernel} on `stream`; no host synchronisation inside.
 int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df, const void *d_T,

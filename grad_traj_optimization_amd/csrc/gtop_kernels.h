@@ -74,4 +74,13 @@ hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const doub
 hipError_t gtop_launch_mma_update(const GtopMmaState &st, int B, int n, const double *fcur, const double *gcur,
                                   hipStream_t stream);
 
+// ---- setup + post-processing (gtop_setup.hip), fp64 ----
+#define GTOP_TRAJ_STATS 9   // time_sum, length, jerk, mean_v, max_v, mean_a, max_a, acc_cost, n_samples
+hipError_t gtop_launch_setup_paths(int B, int m, const double *wp, double mean_v, double init_time, double *T,
+                                   double *Df, double *x0, hipStream_t stream);
+hipError_t gtop_launch_coefficients(int B, int m, const double *x, const double *Df, const double *T, int t_stride,
+                                    double *coeff, hipStream_t stream);
+hipError_t gtop_launch_eval_trajectories(int B, int m, const double *coeff, const double *T, int t_stride,
+                                         double dt_sample, double *out, hipStream_t stream);
+
 #endif  // GTOP_KERNELS_H_

@@ -36,6 +36,9 @@ namespace {
 #ifndef GTOP_SAMPLE_UNROLL
 #define GTOP_SAMPLE_UNROLL 1     // unroll factor of the per-lane sample loop (tuning knob)
 #endif
+#ifndef GTOP_F32_MIN_WAVES
+#define GTOP_F32_MIN_WAVES 3
+#endif
 #ifdef GTOP_WAVES_PER_EU         // register budget: 512 / GTOP_WAVES_PER_EU VGPRs per lane
 #define GTOP_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(GTOP_WAVES_PER_EU)))
 #else
@@ -402,8 +405,13 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
 //                              (small, latency-bound batches)
 //   SPL = 3, NW = 1, TPB = 1 : one wavefront per trajectory (60/64 lanes)
 //   SPL = 15, NW = 1, TPB = 5: 2 lanes per segment, 5 trajectories per wavefront
+// Register budget: the fp32 bodies fit 128 VGPRs (4 waves per SIMD) with at most
+// a couple of spilled dwords; the fp64 bodies need their ~190.
+template <typename R> struct MinWaves { static constexpr int v = 2; };
+template <> struct MinWaves<float> { static constexpr int v = GTOP_F32_MIN_WAVES; };
+
 template <typename R, bool DYN, int SPL>
-__global__ void __launch_bounds__(512) GTOP_WAVES_PER_EU_ATTR
+__global__ void __launch_bounds__(512, (MinWaves<R>::v)) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront

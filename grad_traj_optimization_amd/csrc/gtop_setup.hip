@@ -1,0 +1,210 @@
+// gtop_setup.hip — per-problem setup and post-processing on gfx950, batched.
+//
+// (1) setup_paths: what GradTrajOptimizer::setPath leaves behind for the
+//     callback (src/grad_traj_optimizer.cpp:67-110 of
+//     EpicOne1/grad_traj_optimization): segment_time (:73-81), Df and the
+//     straight-line Dp (src/qp_generator.cpp:199-221, :407-451), for B
+//     waypoint lists at once.  L and R are never formed: the evaluation kernel
+//     derives what it needs from segment_time.
+// (2) eval_trajectories: the post-processing the reference's node runs on the
+//     optimised polynomials (include/grad_traj_optimization/polynomial_traj.hpp:
+//     getTraj/getLength :69-92, getAccCost :96-109, getJerk :111-142,
+//     getMeanAndMaxVel :144-173, getMeanAndMaxAcc :175-204), one lane per
+//     trajectory, statement order kept (including the functions' quirks, see
+//     the comments) so that results match the CPU restatement.
+// Both are setup/report-side, HBM/latency bound, nowhere near the hot path.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gtop_kernels.h"
+
+#pragma clang fp contract(off)   // keep the reference's unfused arithmetic (bit-exact setup)
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+setup_paths_kernel(int B, int m, const double *__restrict__ wp, double mean_v, double init_time,
+                   double *__restrict__ T, double *__restrict__ Df, double *__restrict__ x0) {
+  const int ndp = 3 * m - 3, n = 3 * ndp;
+  const int per = m + 18 + n;   // outputs per trajectory
+  const size_t total = (size_t)B * per;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(q / per);
+    int i = (int)(q - (size_t)b * per);
+    const double *p = wp + (size_t)b * (m + 1) * 3;
+    if (i < m) {
+      // :73-81 — `i == segment_time.size()` never holds inside the loop: only segment 0 gets init_time
+      const double dx = p[i * 3] - p[(i + 1) * 3], dy = p[i * 3 + 1] - p[(i + 1) * 3 + 1],
+                   dz = p[i * 3 + 2] - p[(i + 1) * 3 + 2];
+      const double len = sqrt(dx * dx + dy * dy + dz * dz);
+      T[(size_t)b * m + i] = (i == 0 || i == m) ? len / mean_v + init_time : len / mean_v;
+      continue;
+    }
+    i -= m;
+    if (i < 18) {
+      // getInitialD, src/qp_generator.cpp:418-431: [p_start, 0, 0, p_end, 0, 0] per axis
+      const int axis = i / 6, j = i - axis * 6;
+      Df[(size_t)b * 18 + i] = (j == 0) ? p[axis] : (j == 3 ? p[m * 3 + axis] : 0.0);
+      continue;
+    }
+    i -= 18;
+    {
+      // :433-439 with the straight-line D of :204-221: interior positions, zero vel/acc;
+      // layout i + axis*num_dp (src/grad_traj_optimizer.cpp:182-187)
+      const int axis = i / ndp, c = i - axis * ndp, w = c / 3 + 1, der = c - 3 * (w - 1);
+      x0[(size_t)b * n + i] = (der == 0) ? p[w * 3 + axis] : 0.0;
+    }
+  }
+}
+
+// value of sum_j c[j] t^j the way PolynomialTraj::evaluate forms it
+// (polynomial_traj.hpp:57-66): tv(order-1-i) = pow(t, i), pt = tv . c_descending
+__device__ __forceinline__ double poly_eval(const double *c, double t) {
+  double s = 0.0;
+  for (int i = 5; i >= 0; --i) s += pow(t, (double)i) * c[i];   // dot over descending powers: t^5 c5 first
+  return s;
+}
+
+__global__ void __launch_bounds__(64)
+eval_trajectories_kernel(int B, int m, const double *__restrict__ coeff, const double *__restrict__ T,
+                         int t_stride, double dt_sample, double *__restrict__ out /*[B][GTOP_TRAJ_STATS]*/) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double *cf = coeff + (size_t)b * m * 18;   // row s = [cx0..5 | cy0..5 | cz0..5], ascending powers
+  const double *ts = T + (size_t)b * t_stride;
+  double time_sum = 0.0;                            // init(), :37-43
+  for (int s = 0; s < m; ++s) time_sum += ts[s];
+
+  // getTraj + getLength (:69-92): samples every dt_sample (0.01 in the reference), eval_t accumulated
+  double length = 0.0, pl[3] = {0, 0, 0};
+  int nsamp = 0;
+  for (double eval_t = 0.0; eval_t <= time_sum; eval_t += dt_sample) {
+    double t = eval_t;
+    int idx = 0;
+    while (idx < m - 1 && ts[idx] <= t) {   // :48-51; the reference walks off the end when t == time_sum exactly,
+      t -= ts[idx];                          // here the last segment is extended instead
+      ++idx;
+    }
+    double pn[3];
+    for (int a = 0; a < 3; ++a) pn[a] = poly_eval(cf + idx * 18 + 6 * a, t);
+    if (nsamp > 0) {
+      const double dx = pn[0] - pl[0], dy = pn[1] - pl[1], dz = pn[2] - pl[2];
+      length += sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    pl[0] = pn[0]; pl[1] = pn[1]; pl[2] = pn[2];
+    ++nsamp;
+  }
+
+  // getAccCost (:96-109): um = 2 * (coefficient of t^2) = a(0) per segment
+  double acc_cost = 0.0;
+  for (int s = 0; s < m; ++s) {
+    const double ux = 2 * cf[s * 18 + 2], uy = 2 * cf[s * 18 + 8], uz = 2 * cf[s * 18 + 14];
+    acc_cost += (ux * ux + uy * uy + uz * uz) * ts[s];
+  }
+
+  // getJerk (:111-142): c' M c with M(i,j) = i(i-1)(i-2) j(j-1)(j-2) ts^(i+j-5) / (i+j-5), i,j = 3..5
+  double jerk = 0.0;
+  for (int s = 0; s < m; ++s) {
+    for (int a = 0; a < 3; ++a) {
+      const double *c = cf + s * 18 + 6 * a;
+      double acc = 0.0;
+      for (int j = 3; j < 6; ++j) {      // (c' M)(j) then . c, as Eigen evaluates c.transpose() * M * c
+        double col = 0.0;
+        for (int i = 3; i < 6; ++i) {
+          const double di = i, dj = j;
+          col += c[i] * (di * (di - 1) * (di - 2) * dj * (dj - 1) * (dj - 2) * pow(ts[s], di + dj - 5) / (di + dj - 5));
+        }
+        acc += col * c[j];
+      }
+      jerk += acc;
+    }
+  }
+
+  // getMeanAndMaxVel / Acc (:144-204).  Quirk kept: the time vector is built from
+  // pow(ts, i) — the segment DURATION, not eval_t — so every sample of a segment is
+  // its end-point velocity / acceleration; the loop only sets how often it is counted.
+  double mean_v = 0.0, max_v = -1.0, mean_a = 0.0, max_a = -1.0;
+  int num_v = 0, num_a = 0;
+  for (int s = 0; s < m; ++s) {
+    double vel[3], acc[3];
+    for (int a = 0; a < 3; ++a) {
+      const double *c = cf + s * 18 + 6 * a;
+      double sv = 0.0, sa = 0.0;
+      for (int i = 0; i < 5; ++i) sv += pow(ts[s], (double)i) * ((double)(i + 1) * c[i + 1]);
+      for (int i = 0; i < 4; ++i) sa += pow(ts[s], (double)i) * ((double)((i + 2) * (i + 1)) * c[i + 2]);
+      vel[a] = sv;
+      acc[a] = sa;
+    }
+    const double vn = sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+    const double an = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
+    for (double eval_t = 0.0; eval_t < ts[s]; eval_t += dt_sample) {
+      mean_v += vn;
+      if (vn > max_v) max_v = vn;
+      ++num_v;
+      mean_a += an;
+      if (an > max_a) max_a = an;
+      ++num_a;
+    }
+  }
+  mean_v = mean_v / (double)num_v;
+  mean_a = mean_a / (double)num_a;
+
+  double *o = out + (size_t)b * GTOP_TRAJ_STATS;
+  o[0] = time_sum; o[1] = length; o[2] = jerk; o[3] = mean_v; o[4] = max_v;
+  o[5] = mean_a; o[6] = max_a; o[7] = acc_cost; o[8] = (double)nsamp;
+}
+
+// coefficients from derivatives for B trajectories (getCoefficientFromDerivative,
+// src/grad_traj_optimizer.cpp:253-279): one lane per (trajectory, segment, axis)
+__global__ void __launch_bounds__(256)
+coefficients_kernel(int B, int m, const double *__restrict__ x, const double *__restrict__ Df,
+                    const double *__restrict__ T, int t_stride, double *__restrict__ coeff) {
+  const int ndp = 3 * m - 3, n = 3 * ndp;
+  const size_t total = (size_t)B * m * 3;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(q / (3 * m));
+    const int r = (int)(q - (size_t)b * 3 * m), s = r / 3, k = r - 3 * s;
+    const double *xb = x + (size_t)b * n + (size_t)k * ndp, *df = Df + (size_t)b * 18 + k * 6;
+    auto wpd = [&](int j, int der) -> double {
+      if (j == 0) return df[der];
+      if (j == m) return df[3 + der];
+      return xb[3 * (j - 1) + der];
+    };
+    const double p0 = wpd(s, 0), v0 = wpd(s, 1), a0 = wpd(s, 2);
+    const double pT = wpd(s + 1, 0), vT = wpd(s + 1, 1), aT = wpd(s + 1, 2);
+    const double Ts = T[(size_t)b * t_stride + s], T2 = Ts * Ts, iT = 1.0 / Ts, iT3 = iT * iT * iT;
+    const double P = pT - p0 - v0 * Ts - 0.5 * a0 * T2;
+    const double V = (vT - v0 - a0 * Ts) * Ts;
+    const double A = (aT - a0) * T2;
+    double *c = coeff + ((size_t)b * m + s) * 18 + 6 * k;
+    c[0] = p0; c[1] = v0; c[2] = 0.5 * a0;
+    c[3] = (10 * P - 4 * V + 0.5 * A) * iT3;
+    c[4] = (-15 * P + 7 * V - A) * (iT3 * iT);
+    c[5] = (6 * P - 3 * V + 0.5 * A) * (iT3 * iT * iT);
+  }
+}
+
+}  // namespace
+
+hipError_t gtop_launch_setup_paths(int B, int m, const double *wp, double mean_v, double init_time, double *T,
+                                   double *Df, double *x0, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(setup_paths_kernel, dim3(1024), dim3(256), 0, stream, B, m, wp, mean_v, init_time, T, Df, x0);
+  return hipGetLastError();
+}
+
+hipError_t gtop_launch_coefficients(int B, int m, const double *x, const double *Df, const double *T, int t_stride,
+                                    double *coeff, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(coefficients_kernel, dim3(1024), dim3(256), 0, stream, B, m, x, Df, T, t_stride, coeff);
+  return hipGetLastError();
+}
+
+hipError_t gtop_launch_eval_trajectories(int B, int m, const double *coeff, const double *T, int t_stride,
+                                         double dt_sample, double *out, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(eval_trajectories_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, B, m, coeff, T, t_stride,
+                     dt_sample, out);
+  return hipGetLastError();
+}

@@ -116,6 +116,21 @@ int gtop_get_sdf(gtop_ctx *ctx, double *dist_host, int grid_out[3]);
 int gtop_set_problem(gtop_ctx *ctx, int B, int m, const double *segment_time,
                      int time_stride, const double *Df);
 
+/* Replaces GradTrajOptimizer::setPath for B waypoint lists at once
+ * (src/grad_traj_optimizer.cpp:67-110): segment times (:73-81: length/mean_v,
+ * + init_time on the first segment only), Df and the straight-line initial Dp
+ * (src/qp_generator.cpp:199-221, :407-451), computed on the device.
+ * waypoints: B x (m+1) x 3.  gtop_set_paths makes the result the context's
+ * problem (as gtop_set_problem would) and returns the start point x0 (B*n, may
+ * be NULL); gtop_setup_paths_device writes device buffers and touches no state.
+ * gtop_get_problem reads segment_time (B*m, or m when shared) and Df (B*18) back. */
+int gtop_set_paths(gtop_ctx *ctx, int B, int m, const double *waypoints,
+                   double mean_v, double init_time, double *x0);
+int gtop_setup_paths_device(gtop_ctx *ctx, int B, int m, const void *d_waypoints,
+                            double mean_v, double init_time, void *d_T,
+                            void *d_Df, void *d_x0, void *hip_stream);
+int gtop_get_problem(gtop_ctx *ctx, double *segment_time, double *Df);
+
 /* ---- evaluation ----------------------------------------------------- */
 
 /* Batched form of GradTrajOptimizer::costFunc / getCostAndGradient
@@ -166,6 +181,34 @@ int gtop_optimize_device(gtop_ctx *ctx, int B, int m, void *d_x,
                          const void *d_Df, const void *d_T, int time_stride,
                          const void *d_lb, const void *d_ub, int max_evals,
                          void *d_min_cost, void *hip_stream);
+
+/* ---- post-processing ------------------------------ */
+
+/* Batched GradTrajOptimizer::getCoefficient / getCoefficientFromDerivative
+ * (src/grad_traj_optimizer.cpp:245-279): coeff is B x m x 18, row s =
+ * [cx0..5 | cy0..5 | cz0..5], ascending powers. */
+int gtop_coefficients_device(gtop_ctx *ctx, int B, int m, const void *d_x,
+                             const void *d_Df, const void *d_T, int time_stride,
+                             void *d_coeff, void *hip_stream);
+
+/* The evaluation src/opti_node.cpp:135-142 runs on the optimised polynomials
+ * through PolynomialTraj (include/grad_traj_optimization/polynomial_traj.hpp):
+ * stats is B x GTOP_TRAJ_STATS doubles per trajectory =
+ *   [getTimeSum, getLength (samples every dt_sample; the reference uses 0.01),
+ *    getJerk, mean_v, max_v (getMeanAndMaxVel), mean_a, max_a
+ *    (getMeanAndMaxAcc), getAccCost, number of getTraj samples].
+ * The functions' quirks are kept (mean/max velocity and acceleration are
+ * evaluated at each segment's END time, weighted by its sample count, as
+ * :158-159 / :189-190 compute them). */
+#define GTOP_TRAJ_STATS 9
+int gtop_eval_trajectories_device(gtop_ctx *ctx, int B, int m, const void *d_coeff,
+                                  const void *d_T, int time_stride,
+                                  double dt_sample, void *d_stats,
+                                  void *hip_stream);
+/* Host-buffer form for the context's problem: coefficients (may be NULL) and
+ * stats (may be NULL) of the first B trajectories at free variables x. */
+int gtop_trajectory_stats(gtop_ctx *ctx, int B, const double *x, double dt_sample,
+                          double *coeff, double *stats);
 
 /* ---- bookkeeping the reference keeps inside the callback ------------ */
 

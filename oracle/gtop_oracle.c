@@ -677,3 +677,117 @@ double oracle_eval_batch(int B, int m, const double *T, int t_stride,
   free(Rs);
   return t1 - t0;
 }
+
+/* ------------------------------------------------------------------ */
+/* post-processing: PolynomialTraj                                     */
+/* ------------------------------------------------------------------ */
+
+/* include/grad_traj_optimization/polynomial_traj.hpp:46-66 — evaluate(t) on
+ * coefficients in ASCENDING order c[0..5] (the node reverses them into
+ * descending order, src/opti_node.cpp:118-120, and evaluate() pairs
+ * tv(order-1-i) = pow(t,i) with them, i.e. a dot product that starts at t^5). */
+static double traj_poly_eval(const double *c, double t) {
+  double s = 0.0;
+  for (int i = 5; i >= 0; --i) s += pow(t, (double)i) * c[i];
+  return s;
+}
+
+/* out[9] = time_sum, length, jerk, mean_v, max_v, mean_a, max_a, acc_cost, n_samples.
+ * coeff: m x 18 (row s = [cx0..5 | cy0..5 | cz0..5]).  dt_sample = 0.01 in the reference.
+ * Convention where the reference has UB: evaluate() walks past the last segment when
+ * t == time_sum exactly (:48-51); the last segment is extended instead. */
+void oracle_traj_stats(int m, const double *coeff, const double *T, double dt_sample, double *out) {
+  double time_sum = 0.0; /* :37-43 */
+  for (int i = 0; i < m; ++i) time_sum += T[i];
+
+  double length = 0.0, pl[3] = {0, 0, 0}; /* getTraj :69-78 + getLength :80-92 */
+  int nsamp = 0;
+  for (double eval_t = 0.0; eval_t <= time_sum; eval_t += dt_sample) {
+    double t = eval_t;
+    int idx = 0;
+    while (idx < m - 1 && T[idx] <= t) {
+      t -= T[idx];
+      ++idx;
+    }
+    double pn[3];
+    for (int a = 0; a < 3; ++a) pn[a] = traj_poly_eval(coeff + idx * 18 + 6 * a, t);
+    if (nsamp > 0) {
+      double dx = pn[0] - pl[0], dy = pn[1] - pl[1], dz = pn[2] - pl[2];
+      length += sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    pl[0] = pn[0]; pl[1] = pn[1]; pl[2] = pn[2];
+    ++nsamp;
+  }
+
+  double acc_cost = 0.0; /* getAccCost :96-109: um = 2*c[order-3] with descending c = 2*c2 */
+  for (int s = 0; s < m; ++s) {
+    double ux = 2 * coeff[s * 18 + 2], uy = 2 * coeff[s * 18 + 8], uz = 2 * coeff[s * 18 + 14];
+    acc_cost += (ux * ux + uy * uy + uz * uz) * T[s];
+  }
+
+  double jerk = 0.0; /* getJerk :111-142 */
+  for (int s = 0; s < m; ++s) {
+    double M[6][6];
+    memset(M, 0, sizeof(M));
+    for (double i = 3; i < 6; i += 1)
+      for (double j = 3; j < 6; j += 1)
+        M[(int)i][(int)j] = i * (i - 1) * (i - 2) * j * (j - 1) * (j - 2) * pow(T[s], i + j - 5) / (i + j - 5);
+    for (int a = 0; a < 3; ++a) {
+      const double *c = coeff + s * 18 + 6 * a;
+      double acc = 0.0; /* (c' M) c */
+      for (int j = 3; j < 6; ++j) {
+        double col = 0.0;
+        for (int i = 3; i < 6; ++i) col += c[i] * M[i][j];
+        acc += col * c[j];
+      }
+      jerk += acc;
+    }
+  }
+
+  /* getMeanAndMaxVel :144-173, getMeanAndMaxAcc :175-204 — tv(i) = pow(ts, i): the
+   * segment duration, not eval_t (kept as written) */
+  double mean_v = 0.0, max_v = -1.0, mean_a = 0.0, max_a = -1.0;
+  int num_v = 0, num_a = 0;
+  for (int s = 0; s < m; ++s) {
+    double vel[3], acc[3];
+    for (int a = 0; a < 3; ++a) {
+      const double *c = coeff + s * 18 + 6 * a;
+      double sv = 0.0, sa = 0.0;
+      for (int i = 0; i < 5; ++i) sv += pow(T[s], (double)i) * ((double)(i + 1) * c[i + 1]);
+      for (int i = 0; i < 4; ++i) sa += pow(T[s], (double)i) * ((double)((i + 2) * (i + 1)) * c[i + 2]);
+      vel[a] = sv;
+      acc[a] = sa;
+    }
+    double vn = sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+    double an = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
+    for (double eval_t = 0.0; eval_t < T[s]; eval_t += dt_sample) {
+      mean_v += vn;
+      if (vn > max_v) max_v = vn;
+      ++num_v;
+      mean_a += an;
+      if (an > max_a) max_a = an;
+      ++num_a;
+    }
+  }
+  mean_v = mean_v / (double)num_v;
+  mean_a = mean_a / (double)num_a;
+
+  out[0] = time_sum; out[1] = length; out[2] = jerk; out[3] = mean_v; out[4] = max_v;
+  out[5] = mean_a; out[6] = max_a; out[7] = acc_cost; out[8] = (double)nsamp;
+}
+
+/* getCoefficientFromDerivative (src/grad_traj_optimizer.cpp:253-279): coe = L d, m x 18 */
+void oracle_coefficients(int m, const double *L, const double *Df, const double *x, double *coe) {
+  const int num_dp = 3 * m - 3, nd = 6 + num_dp, n6 = 6 * m;
+  double *d = dalloc((size_t)nd);
+  for (int a = 0; a < 3; ++a) {
+    for (int j = 0; j < 6; ++j) d[j] = Df[a * 6 + j];
+    for (int j = 0; j < num_dp; ++j) d[6 + j] = x[j + num_dp * a];
+    for (int r = 0; r < n6; ++r) {
+      double s = 0;
+      for (int i = 0; i < nd; ++i) s += L[r * nd + i] * d[i];
+      coe[(r / 6) * 18 + 6 * a + (r % 6)] = s;
+    }
+  }
+  free(d);
+}

@@ -58,6 +58,9 @@ double oracle_eval_batch(int B, int m, const double *T, int t_stride,
                          const oracle_sdf *S, const double *x, double *cost,
                          double *grad, int reps, int nthreads);
 
+void oracle_traj_stats(int m, const double *coeff, const double *T, double dt_sample, double *out);
+void oracle_coefficients(int m, const double *L, const double *Df, const double *x, double *coe);
+
 #ifdef __cplusplus
 }
 #endif

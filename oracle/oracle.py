@@ -79,6 +79,10 @@ def lib():
                                         C.POINTER(OracleParams), C.POINTER(OracleSdf),
                                         dp, dp, dp, C.c_int, C.c_int]
         L.oracle_eval_batch.restype = C.c_double
+        L.oracle_traj_stats.argtypes = [C.c_int, dp, dp, C.c_double, dp]
+        L.oracle_traj_stats.restype = None
+        L.oracle_coefficients.argtypes = [C.c_int, dp, dp, dp, dp]
+        L.oracle_coefficients.restype = None
         _lib = L
     return _lib
 
@@ -212,3 +216,22 @@ def eval_batch(T, Df, x, sdf, params, reps=1, nthreads=1):
     if sec < 0:
         raise ValueError("oracle_eval_batch failed")
     return cost, grad, sec
+
+
+def coefficients(T, Df, x, L=None):
+    """getCoefficientFromDerivative: (m, 18) coefficients, ascending powers per axis."""
+    T = _f64(T)
+    m = T.shape[0]
+    if L is None:
+        L = generator(T)["L"]
+    coe = np.zeros((m, 18))
+    lib().oracle_coefficients(m, _p(_f64(L)), _p(_f64(Df)), _p(_f64(x)), _p(coe))
+    return coe
+
+
+def traj_stats(coeff, T, dt_sample=0.01):
+    """PolynomialTraj evaluation: [time_sum, length, jerk, mean_v, max_v, mean_a, max_a, acc_cost, n_samples]."""
+    T = _f64(T)
+    out = np.zeros(9)
+    lib().oracle_traj_stats(T.shape[0], _p(_f64(coeff)), _p(T), float(dt_sample), _p(out))
+    return out

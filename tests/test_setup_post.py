@@ -1,0 +1,70 @@
+"""SURVEY §8f rows f3 (on-device problem setup) and f4 (post-processing of the
+optimised polynomials) against the oracle's restatement of
+src/grad_traj_optimizer.cpp:67-110 / src/qp_generator.cpp:199-221,:407-451 and
+include/grad_traj_optimization/polynomial_traj.hpp."""
+import numpy as np
+import pytest
+
+from grad_traj_optimization_amd import problem
+from tests import scenes
+
+
+def test_oracle_traj_stats_known_answers(oracle_mod):
+    """A single straight constant-velocity run: closed-form length, zero jerk."""
+    m = 3
+    T = np.array([1.0, 0.5, 0.75])
+    coeff = np.zeros((m, 18))
+    pos = 0.0
+    for s in range(m):
+        coeff[s, 0], coeff[s, 1] = pos, 2.0          # x(t) = pos + 2 t
+        coeff[s, 6 + 1] = 1.0                        # y(t) = t (restarts per segment: a kink, fine)
+        pos += 2.0 * T[s]
+    st = oracle_mod.traj_stats(coeff, T)
+    assert st[0] == T.sum() and st[2] == 0.0 and st[7] == 0.0       # time, jerk, acc cost
+    assert abs(st[3] - np.sqrt(5.0)) < 1e-12 and abs(st[4] - np.sqrt(5.0)) < 1e-12
+    assert st[5] == 0.0 and st[6] == 0.0
+    assert st[8] == 226                                               # 0.00 .. 2.25 in steps of 0.01 (accumulated)
+    # jerk of x = t^3 over T: int (6)^2 dt = 36 T
+    c2 = np.zeros((2, 18))
+    c2[:, 3] = 1.0
+    st2 = oracle_mod.traj_stats(c2, np.array([2.0, 1.0]))
+    assert abs(st2[2] - 36 * 3.0) < 1e-9
+    # the end-time quirk: velocity of x = t^3 is reported as 3 T^2 for every sample of a segment
+    assert abs(st2[4] - 12.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_set_paths_matches_setpath_restatement(gtop, oracle_mod):
+    mp = problem.make_map((40, 40, 20), density=0.0, seed=1)
+    ctx = gtop.GtopContext(device=0)
+    for m in (2, 6, 10):
+        b = problem.make_trajectories(33, m, mp, seed=m, step_len=(0.5, 1.5), margin=0.4)
+        x0 = ctx.set_paths(b.waypoints, mean_v=1.8, init_time=0.3)
+        T, Df = ctx.get_problem()
+        for i in range(33):
+            assert np.array_equal(T[i], oracle_mod.segment_time(b.waypoints[i]))          # bit-exact
+            Df_ref, Dp_ref = oracle_mod.initial_d(b.waypoints[i])
+            assert np.array_equal(Df[i], Df_ref) and np.array_equal(x0[i], Dp_ref.reshape(-1))
+    # the reference's own scene: first segment alone carries init_time
+    x0 = ctx.set_paths(scenes.OPTI_NODE_PATH[None], 1.8, 0.3)
+    T, Df = ctx.get_problem()
+    assert T[0, 0] == np.sqrt(2.0) / 1.8 + 0.3 and T[0, 9] == np.sqrt(2.0) / 1.8
+    with pytest.raises(gtop.GtopError):
+        ctx.set_paths(np.zeros((1, 2, 3)))            # 2 waypoints -> m = 1
+
+
+@pytest.mark.gpu
+def test_trajectory_stats_and_coefficients(gtop, oracle_mod):
+    mp = problem.make_map((40, 40, 20), density=0.0, seed=1)
+    ctx = gtop.GtopContext(device=0)
+    for m in (2, 6, 11):
+        b = problem.make_trajectories(17, m, mp, seed=50 + m, step_len=(0.5, 1.5), margin=0.4)
+        x = b.x + np.random.default_rng(m).normal(0, 0.3, b.x.shape)     # some velocity / acceleration
+        ctx.set_problem(b.T, b.Df)
+        coeff, stats = ctx.trajectory_stats(x, dt_sample=0.01)
+        for i in range(17):
+            c_ref = oracle_mod.coefficients(b.T[i], b.Df[i], x[i])
+            assert np.allclose(coeff[i], c_ref, rtol=1e-9, atol=1e-9 * np.abs(c_ref).max())
+            s_ref = oracle_mod.traj_stats(coeff[i], b.T[i], 0.01)
+            assert stats[i, 8] == s_ref[8] and stats[i, 0] == s_ref[0]       # sample count, time sum: exact
+            assert np.allclose(stats[i, 1:8], s_ref[1:8], rtol=1e-9, atol=1e-12)
