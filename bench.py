@@ -319,6 +319,7 @@ def extras(args, ctx, batch, mp, x, Df, T, tdtype, dev):
     out = {"workloads": []}
     if args.grid == 200 and args.segments == 6:
         big = problem.make_trajectories(16384, 6, mp, seed=7)
+        big = problem.permute(big, problem.spatial_order(big.waypoints, mp.origin, mp.map_size))
         for dt, name in ((torch.float32, "f32"), (torch.float64, "f64")):
             xb = torch.tensor(big.x, dtype=dt, device=dev)
             Dfb = torch.tensor(big.Df.reshape(-1, 18), dtype=dt, device=dev)
