@@ -687,7 +687,11 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
 #pragma unroll
             for (int v = 0; v < kRedChunk; ++v)
               if (v < cn) myred[v * kRedStride + lane] = acc[c0 + v];
-            __syncthreads();
+            // The tile belongs to this wavefront alone (writers and readers are its own
+            // lanes), and a wavefront's LDS operations execute in order: no workgroup
+            // barrier, only a compiler-level ordering point.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             // each lane owns up to kRdr (segment slot, value) sums; all tile reads are
             // issued before any result is stored (one LDS round trip, not kRdr)
             constexpr int kRdr = (SPW * kRedChunk + 63) / 64;
@@ -710,14 +714,15 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
                 else ccol[Sr] = sums[u];
               }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // tile is rewritten by the next chunk / pass
+            __builtin_amdgcn_wave_barrier();
           }
         }
       }
     } else {
       for (int q = tid; q < 18 * nseg; q += nthr) Gc[q] = (R)0;   // |wc| < 1e-4: no collision term (:346)
     }
-    if (LPS == 1) __syncthreads();
+    __syncthreads();   // Gc / ccol of every wavefront are complete
     GTOP_STAMP(4);
 
     // ---- phase 3: coefficient space -> derivative space (A_s^-T) ----

@@ -22,7 +22,12 @@ def oracle_mod():
 
 @pytest.fixture(scope="session")
 def gtop():
-    """The product package; the C-ABI library must already be built in-tree."""
+    """The product package.  The C-ABI library is normally built in-tree by
+    __graft_entry__.build(); on a fresh checkout build it here (hipcc
+    cross-compiles for gfx950 without a GPU)."""
     import grad_traj_optimization_amd as g
+    if not os.path.exists(g.library_path()):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "grad_traj_optimization_amd", "csrc"), "-s", "all"])
     g.load_library()
     return g
