@@ -105,6 +105,7 @@ def load_library():
         "gtop_get_cost_curve": (C.c_int, [vp, dp, dp, C.c_int, ip]),
         "gtop_clear_cost_curve": (C.c_int, [vp]),
         "gtop_set_launch_geometry": (C.c_int, [vp, C.c_int, C.c_int]),
+        "gtop_set_optimizer_fusion": (C.c_int, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -207,6 +208,9 @@ class GtopContext:
             m, stride = T.shape[0], 0
         self._chk(self._L.gtop_set_problem(self._h, B, m, _p(T), stride, _p(Df)))
         self.B, self.m = B, m
+
+    def set_optimizer_fusion(self, fused=True):
+        self._chk(self._L.gtop_set_optimizer_fusion(self._h, int(bool(fused))))
 
     def set_launch_geometry(self, waves=0, samples_per_lane=0):
         self._chk(self._L.gtop_set_launch_geometry(self._h, int(waves), int(samples_per_lane)))

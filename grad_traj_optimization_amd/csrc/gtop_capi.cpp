@@ -53,6 +53,7 @@ struct gtop_ctx {
 
   int waves = 0;   // 0 = auto
   int spl = 0;     // samples per lane, 0 = auto
+  bool fuse_mma = true;     // optimizer: MMA update fused into the evaluation kernel (tuning/debug knob)
   int auto_spl_large = 6;   // what auto picks for B >= 4096 (m = 6: two trajectories per wavefront)
 
   // bookkeeping of the callback (grad_traj_optimizer.cpp:284, :436, :439-447)
@@ -587,10 +588,29 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
   st.rho = c->mma_scal; st.minf = st.rho + B; st.gval = st.minf + B; st.wval = st.gval + B;
   st.k = c->mma_int; st.state = st.k + B;
   HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
+  int waves, spl, tpb;
+  launch_geometry(c, B, m, &waves, &spl, &tpb);
+  const bool fused = c->fuse_mma && (spl == 1 || spl == 6);
   for (int it = 0; it < max_evals; ++it) {
-    if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s)))
-      return rc;
-    HIPCHK(c, gtop_launch_mma_update(st, B, (int)n, c->mma_f, c->mma_g, s));
+    if (fused) {
+      // one launch per iteration: the evaluation kernel runs the MMA update as its epilogue
+      GtopKernelArgs<double> a;
+      fill_args(c, a);
+      a.sdf = c->sdf64;
+      a.x = st.xcur;
+      a.Df = static_cast<const double *>(d_Df);
+      a.T = static_cast<const double *>(d_T);
+      a.cost = c->mma_f;
+      a.grad = c->mma_g;
+      a.B = B; a.m = m; a.t_stride = time_stride;
+      while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, sizeof(double)) > 64 * 1024) --tpb;
+      a.tpb = tpb;
+      HIPCHK(c, gtop_launch_eval_mma(a, st, waves, spl, c->prm.enable_dyn != 0, 1 << 20, s));
+    } else {
+      if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s)))
+        return rc;
+      HIPCHK(c, gtop_launch_mma_update(st, B, (int)n, c->mma_f, c->mma_g, s));
+    }
   }
   HIPCHK(c, hipMemcpyAsync(d_x, st.x, bn * sizeof(double), hipMemcpyDeviceToDevice, s));
   if (d_minf) HIPCHK(c, hipMemcpyAsync(d_minf, st.minf, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -679,6 +699,12 @@ int gtop_clear_cost_curve(gtop_ctx *c) {
   c->vec_cost.clear();   // grad_traj_optimizer.cpp:192-194
   c->vec_time.clear();
   c->time_start = std::chrono::steady_clock::now();
+  return GTOP_OK;
+}
+
+int gtop_set_optimizer_fusion(gtop_ctx *c, int fused) {
+  if (!c) return GTOP_ERR_INVALID;
+  c->fuse_mma = fused != 0;
   return GTOP_OK;
 }
 

@@ -1,0 +1,156 @@
+// gtop_device_common.h — device-side helpers shared by the evaluation kernel
+// (gtop_kernels.hip) and the optimizer kernels (gtop_mma.hip).
+#ifndef GTOP_DEVICE_COMMON_H_
+#define GTOP_DEVICE_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include "gtop_kernels.h"
+
+// Wavefront sum on the DPP cross-lane path (no LDS round trips): quad swaps,
+// row shifts, then the two row broadcasts; every lane's contribution ends up in
+// lane 63, which is read back with readlane.  __shfl_xor would go through
+// ds_bpermute (~100+ cycles per step); this is ~10.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float gtop_dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double gtop_dpp_move(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename R>
+__device__ __forceinline__ R gtop_wave_sum(R v) {
+  v += gtop_dpp_move<0xb1>(v);         // quad_perm [1,0,3,2]
+  v += gtop_dpp_move<0x4e>(v);         // quad_perm [2,3,0,1]
+  v += gtop_dpp_move<0x114>(v);        // row_shr:4
+  v += gtop_dpp_move<0x118>(v);        // row_shr:8   -> lane 15 of each row holds the row sum
+  v += gtop_dpp_move<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += gtop_dpp_move<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  if constexpr (sizeof(R) == 8) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+    return __builtin_bit_cast(R, ((unsigned long long)hi << 32) | lo);
+  } else {
+    return __builtin_bit_cast(R, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// One CCSA-MMA update of trajectory b by one wavefront (lanes stride its n
+// variables): consumes f(xcur) and its gradient, decides accept / inner-done,
+// adapts rho and the asymptotes, and writes the next trial point into xcur.
+// Same arithmetic as csrc/mma.hpp (Svanberg 2002 as in NLopt 2.5.0's mma.c,
+// zero nonlinear constraints: the separable minimiser is closed form).
+// state[b]: 0 = first evaluation pending, 1 = inside an inner loop.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void gtop_mma_separable_step(int n, int lane, const double *x, const double *dfdx,
+                                                        const double *sigma, double rho, const double *lb,
+                                                        const double *ub, double *xcur, double &g, double &w) {
+  g = 0.0;
+  w = 0.0;
+  for (int j = lane; j < n; j += 64) {
+    const double sg = sigma[j], xj = x[j];
+    if (sg == 0.0) {
+      xcur[j] = xj;
+      continue;
+    }
+    const double df = dfdx[j];
+    const double sigma2 = sg * sg;
+    const double u = df * sigma2;
+    const double v = fabs(df) * sg + 0.5 * rho;
+    const double q = u / (v * sg);
+    double dx = (u / v) / (-1.0 - sqrt(fabs(1.0 - q * q)));
+    double xc = xj + dx;
+    xc = xc > ub[j] ? ub[j] : (xc < lb[j] ? lb[j] : xc);
+    const double hi = xj + 0.9 * sg, lo = xj - 0.9 * sg;
+    xc = xc > hi ? hi : (xc < lo ? lo : xc);
+    xcur[j] = xc;
+    dx = xc - xj;
+    const double dx2 = dx * dx;
+    const double denominv = 1.0 / (sigma2 - dx2);
+    g += (df * (sigma2 * dx) + (fabs(df) * sg + 0.5 * rho) * dx2) * denominv;
+    w += 0.5 * dx2 * denominv;
+  }
+}
+
+// gcur: this trajectory's gradient at xcur (n values; global or LDS)
+__device__ __forceinline__ void gtop_mma_update_trajectory(const GtopMmaState &st, int b, int n, int lane,
+                                                           double fcur, const double *gcur) {
+  const size_t o = (size_t)b * n;
+  double *x = st.x + o, *xcur = st.xcur + o, *xprev = st.xprev + o, *xprevprev = st.xprevprev + o;
+  double *dfdx = st.dfdx + o, *sigma = st.sigma + o;
+  const double *lb = st.lb + o, *ub = st.ub + o;
+  double rho = st.rho[b], minf = st.minf[b];
+  int k = st.k[b];
+  const int state = st.state[b];
+  bool new_outer;
+
+  if (state == 0) {
+    // f(x0): base point = start (mma.hpp: first evaluation)
+    minf = fcur;
+    for (int j = lane; j < n; j += 64) {
+      x[j] = xcur[j];
+      dfdx[j] = gcur[j];
+    }
+    new_outer = true;
+  } else {
+    const double gval = st.gval[b], wval = st.wval[b];
+    const bool inner_done = gval >= fcur;
+    if (fcur < minf) {   // accept: new base point
+      minf = fcur;
+      for (int j = lane; j < n; j += 64) {
+        x[j] = xcur[j];
+        dfdx[j] = gcur[j];
+      }
+    }
+    if (inner_done) {
+      // end of the outer iteration: relax rho, adapt the asymptotes
+      rho = fmax(0.1 * rho, 1e-5);
+      if (k > 1) {
+        for (int j = lane; j < n; j += 64) {
+          const double dx2 = (xcur[j] - xprev[j]) * (xprev[j] - xprevprev[j]);
+          const double gam = dx2 < 0 ? 0.7 : (dx2 > 0 ? 1.2 : 1.0);
+          double s = sigma[j] * gam;
+          const double range = ub[j] - lb[j];
+          if (!isinf(ub[j]) && !isinf(lb[j])) {
+            s = fmin(s, 10 * range);
+            s = fmax(s, 0.01 * range);
+          }
+          sigma[j] = s;
+        }
+      }
+      new_outer = true;
+    } else {
+      if (fcur > gval) rho = fmin(10 * rho, 1.1 * (rho + (fcur - gval) / wval));
+      new_outer = false;
+    }
+  }
+  if (new_outer) {
+    ++k;
+    for (int j = lane; j < n; j += 64) {
+      if (k > 1) xprevprev[j] = xprev[j];
+      xprev[j] = xcur[j];
+    }
+  }
+  // every lane's writes above are to its own j; the step below reads x/dfdx/sigma
+  // at the same j only, so no cross-lane hazard
+  double g, w;
+  gtop_mma_separable_step(n, lane, x, dfdx, sigma, rho, lb, ub, xcur, g, w);
+  g = gtop_wave_sum(g);
+  w = gtop_wave_sum(w);
+  if (lane == 0) {
+    st.gval[b] = minf + g;
+    st.wval[b] = w;
+    st.rho[b] = rho;
+    st.minf[b] = minf;
+    st.k[b] = k;
+    st.state[b] = 1;
+  }
+}
+
+#endif  // GTOP_DEVICE_COMMON_H_

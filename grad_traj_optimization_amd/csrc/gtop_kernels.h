@@ -32,6 +32,13 @@ struct GtopKernelArgs {
   int step;
 };
 
+// ---- batched CCSA-MMA optimizer state (gtop_mma.hip), all fp64, [B][n] / [B] ----
+struct GtopMmaState {
+  double *x, *xcur, *xprev, *xprevprev, *dfdx, *sigma;   // [B][n]
+  const double *lb, *ub;                                  // [B][n]
+  double *rho, *minf, *gval, *wval;                       // [B]
+  int *k, *state;                                         // [B]
+};
 size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem);
 
 // spl = samples per lane (a divisor of 30); a wavefront then holds
@@ -63,13 +70,9 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, double 
                                   double *dist, int *vws, double *zws, size_t ws_lines,
                                   hipStream_t stream);
 
-// ---- batched CCSA-MMA optimizer state (gtop_mma.hip), all fp64, [B][n] / [B] ----
-struct GtopMmaState {
-  double *x, *xcur, *xprev, *xprevprev, *dfdx, *sigma;   // [B][n]
-  const double *lb, *ub;                                  // [B][n]
-  double *rho, *minf, *gval, *wval;                       // [B]
-  int *k, *state;                                         // [B]
-};
+// fused: cost/gradient at st.xcur + MMA update in one launch (fp64; spl must be 1 or 6)
+hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
+                                bool dyn, int max_blocks, hipStream_t stream);
 hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const double *x0, hipStream_t stream);
 hipError_t gtop_launch_mma_update(const GtopMmaState &st, int B, int n, const double *fcur, const double *gcur,
                                   hipStream_t stream);

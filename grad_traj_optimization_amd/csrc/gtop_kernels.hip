@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gtop_device_common.h"
 #include "gtop_kernels.h"
 
 namespace {
@@ -192,38 +193,8 @@ __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R
   return out ? (R)-1 : dist;   // the caller zeroes the gradient's weight when out (grad := 0)
 }
 
-// Wavefront sum on the DPP cross-lane path (no LDS round trips): quad swaps,
-// row shifts, then the two row broadcasts; every lane's contribution ends up in
-// lane 63, which is read back with readlane.  __shfl_xor would go through
-// ds_bpermute (~100+ cycles per step); this is ~10.
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_move(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
-}
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ double dpp_move(double v) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, true);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, true);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 template <typename R>
-__device__ __forceinline__ R wave_sum(R v) {
-  v += dpp_move<0xb1>(v);         // quad_perm [1,0,3,2]
-  v += dpp_move<0x4e>(v);         // quad_perm [2,3,0,1]
-  v += dpp_move<0x114>(v);        // row_shr:4
-  v += dpp_move<0x118>(v);        // row_shr:8   -> lane 15 of each row holds the row sum
-  v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-  v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-  if constexpr (sizeof(R) == 8) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
-    return __builtin_bit_cast(R, ((unsigned long long)hi << 32) | lo);
-  } else {
-    return __builtin_bit_cast(R, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-  }
-}
+__device__ __forceinline__ R wave_sum(R v) { return gtop_wave_sum(v); }
 
 // sum of N consecutive values as a balanced tree (depth log2 N instead of an
 // N-long dependent chain)
@@ -410,9 +381,14 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
 template <typename R> struct MinWaves { static constexpr int v = 2; };
 template <> struct MinWaves<float> { static constexpr int v = GTOP_F32_MIN_WAVES; };
 
-template <typename R, bool DYN, int SPL>
+//
+// MMA = true (fp64 only) appends the optimizer step: `a.x` is then the trial
+// point st.xcur of the lock-step CCSA-MMA driver, and after cost and gradient of
+// a trajectory are known the same workgroup runs its MMA update
+// (gtop_mma_update_trajectory) — one launch per optimizer iteration.
+template <typename R, bool DYN, int SPL, bool MMA>
 __global__ void __launch_bounds__(512, (MinWaves<R>::v)) GTOP_WAVES_PER_EU_ATTR
-gtop_eval_kernel(const GtopKernelArgs<R> a) {
+gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront
   static_assert(LPS * SPL == kSamples, "SPL must divide 30");
@@ -749,6 +725,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
     // ---- phase 4: gather to the free variables, +1e-5 (:425-432); cost (:417-418) ----
     {
       R *gb = a.grad + (size_t)b0 * n;
+      R *gl = Gs;    // [TPB][n] gradient copy for the fused optimizer step (Gs is dead after phase 3)
+      R *fc = dts;   // [TPB]    cost copy (dts is dead after phase 2)
       for (int q = tid; q < ntraj * n; q += nthr) {
         int tl = 0, i = q;
         while (i >= n) { i -= n; ++tl; }
@@ -758,13 +736,22 @@ gtop_eval_kernel(const GtopKernelArgs<R> a) {
         const R v = gs[((wpt - 1) * 3 + axis) * 6 + 2 * der + 1] +   // end of segment wpt-1
                     gs[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
         gb[q] = v + (R)1e-5;
+        if (MMA) gl[q] = v + (R)1e-5;
       }
-      for (int tl = wave; tl < ntraj; tl += NW) {   // one wavefront shuffle reduction per trajectory
+      for (int tl = wave; tl < ntraj; tl += NW) {   // one wavefront reduction per trajectory
         R part = (R)0;
         for (int i = lane; i < 3 * m; i += 64) part += ws * csm[tl * 3 * m + i];
         for (int i = lane; i < m; i += 64) part += ccol[tl * m + i];
         part = wave_sum(part);
-        if (lane == 0) a.cost[b0 + tl] = part + (R)1e-3;
+        if (lane == 0) {
+          a.cost[b0 + tl] = part + (R)1e-3;
+          if (MMA) fc[tl] = part + (R)1e-3;
+        }
+      }
+      if constexpr (MMA) {
+        __syncthreads();   // gl / fc complete
+        for (int tl = wave; tl < ntraj; tl += NW)
+          gtop_mma_update_trajectory(st, b0 + tl, n, lane, (double)fc[tl], reinterpret_cast<const double *>(gl) + tl * n);
       }
     }
     GTOP_STAMP(6);
@@ -783,27 +770,35 @@ size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem) {
 
 int gtop_eval_segments_per_wave(int spl) { return 64 / (kSamples / spl); }
 
-template <typename R, bool DYN>
-static hipError_t launch_spl(const GtopKernelArgs<R> &args, int waves, int spl, int grid, size_t smem,
-                             hipStream_t stream) {
-  void (*kern)(const GtopKernelArgs<R>) = nullptr;
-  switch (spl) {
-    case 1: kern = gtop_eval_kernel<R, DYN, 1>; break;
-    case 2: kern = gtop_eval_kernel<R, DYN, 2>; break;
-    case 3: kern = gtop_eval_kernel<R, DYN, 3>; break;
-    case 5: kern = gtop_eval_kernel<R, DYN, 5>; break;
-    case 6: kern = gtop_eval_kernel<R, DYN, 6>; break;
-    case 10: kern = gtop_eval_kernel<R, DYN, 10>; break;
-    case 15: kern = gtop_eval_kernel<R, DYN, 15>; break;
-    case 30: kern = gtop_eval_kernel<R, DYN, 30>; break;
-    default: return hipErrorInvalidValue;
+template <typename R, bool DYN, bool MMA>
+static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, int grid,
+                             size_t smem, hipStream_t stream) {
+  void (*kern)(const GtopKernelArgs<R>, const GtopMmaState) = nullptr;
+  if constexpr (MMA) {   // the fused optimizer step is built for the two geometries the auto rule picks
+    switch (spl) {
+      case 1: kern = gtop_eval_kernel<R, DYN, 1, true>; break;
+      case 6: kern = gtop_eval_kernel<R, DYN, 6, true>; break;
+      default: return hipErrorInvalidValue;
+    }
+  } else {
+    switch (spl) {
+      case 1: kern = gtop_eval_kernel<R, DYN, 1, false>; break;
+      case 2: kern = gtop_eval_kernel<R, DYN, 2, false>; break;
+      case 3: kern = gtop_eval_kernel<R, DYN, 3, false>; break;
+      case 5: kern = gtop_eval_kernel<R, DYN, 5, false>; break;
+      case 6: kern = gtop_eval_kernel<R, DYN, 6, false>; break;
+      case 10: kern = gtop_eval_kernel<R, DYN, 10, false>; break;
+      case 15: kern = gtop_eval_kernel<R, DYN, 15, false>; break;
+      case 30: kern = gtop_eval_kernel<R, DYN, 30, false>; break;
+      default: return hipErrorInvalidValue;
+    }
   }
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), smem, stream, args);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), smem, stream, args, st);
   return hipGetLastError();
 }
 
@@ -815,15 +810,22 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, b
   const int groups = (args.B + args.tpb - 1) / args.tpb;
   const int vblocks = 8 * ((groups + 7) / 8);   // the kernel walks 8 XCD-contiguous ranges
   const int grid = vblocks < max_blocks ? vblocks : max_blocks;
-  return dyn ? launch_spl<R, true>(args, waves, spl, grid, smem, stream)
-             : launch_spl<R, false>(args, waves, spl, grid, smem, stream);
+  const GtopMmaState none{};
+  return dyn ? launch_spl<R, true, false>(args, none, waves, spl, grid, smem, stream)
+             : launch_spl<R, false, false>(args, none, waves, spl, grid, smem, stream);
 }
 
-#ifdef GTOP_STAMPS
-extern "C" int gtop_debug_read_stamps(unsigned long long *out /*4096*8*/) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gtop_stamps), sizeof(unsigned long long) * 4096 * 8);
+// cost/gradient at st.xcur + the MMA update, one launch (fp64; spl 1 or 6)
+hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
+                                bool dyn, int max_blocks, hipStream_t stream) {
+  if (args.B <= 0) return hipSuccess;
+  const size_t smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, sizeof(double));
+  const int groups = (args.B + args.tpb - 1) / args.tpb;
+  const int vblocks = 8 * ((groups + 7) / 8);
+  const int grid = vblocks < max_blocks ? vblocks : max_blocks;
+  return dyn ? launch_spl<double, true, true>(args, st, waves, spl, grid, smem, stream)
+             : launch_spl<double, false, true>(args, st, waves, spl, grid, smem, stream);
 }
-#endif
 
 template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, int, bool, int, hipStream_t);
 template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, int, bool, int, hipStream_t);

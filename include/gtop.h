@@ -231,6 +231,10 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
  * fit).  0 = choose from B and m.  Results do not depend on it beyond fp
  * summation order. */
 int gtop_set_launch_geometry(gtop_ctx *ctx, int waves, int samples_per_lane);
+/* Batched optimizer: 1 (default) = the MMA update runs as the epilogue of the
+ * evaluation kernel (one launch per iteration); 0 = separate update launch.
+ * Same arithmetic either way. */
+int gtop_set_optimizer_fusion(gtop_ctx *ctx, int fused);
 
 #ifdef __cplusplus
 }

@@ -146,3 +146,27 @@ def test_optimize_device_api_and_determinism(scene, gtop):
     torch.cuda.synchronize()
     assert torch.equal(c1, out[0][1])            # min_cost is the cost of the returned x
     assert (c1 <= c0).all() and (c1 < 0.5 * c0).float().mean() > 0.9
+
+
+@pytest.mark.parametrize("B,m", [(64, 6), (5000, 6), (300, 12)])
+def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m):
+    """The MMA update as the evaluation kernel's epilogue (one launch per iteration)
+    does the same arithmetic as the two-launch form: bit-identical results."""
+    import torch
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(B, m, mp, seed=900 + m)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    dev = torch.device("cuda:0")
+    Df = torch.tensor(b.Df.reshape(-1, 18), device=dev)
+    T = torch.tensor(b.T, device=dev)
+    lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
+    ctx.set_params()
+    res = []
+    for fused in (True, False):
+        ctx.set_optimizer_fusion(fused)
+        x = torch.tensor(b.x, device=dev)
+        x, c = ctx.optimize_device(x, Df, T, lbt, ubt, 15)
+        torch.cuda.synchronize()
+        res.append((x.clone(), c.clone()))
+    ctx.set_optimizer_fusion(True)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
