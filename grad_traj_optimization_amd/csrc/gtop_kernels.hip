@@ -394,22 +394,22 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   static_assert(LPS * SPL == kSamples, "SPL must divide 30");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *sm = reinterpret_cast<R *>(smem_raw);
-  const int m = a.m, ND = 3 * m + 3, ndp = 3 * m - 3, n = 3 * ndp;
+  const int m = a.m, ndp = 3 * m - 3, n = 3 * ndp;
   const int TPB = a.tpb, MS = TPB * m;       // trajectories / virtual segments per workgroup
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, NW = nthr >> 6;
   const int slot = lane / LPS, li = lane - slot * LPS;   // segment slot in this wave, lane in segment
 
-  R *dv = sm;                // [TPB][3][ND] d = [Df | dp] per axis (:302-323)
-  R *Ts = dv + 3 * ND * TPB; // [MS]       segment_time
+  R *Ts = sm;                // [MS]       segment_time
   R *coef = Ts + MS;         // [MS][3][6] polynomial coefficients (:253-279)
-  R *Gs = coef + 18 * MS;    // [MS][3][6] coefficient-space gradient
+  R *Gs = coef + 18 * MS;    // [MS][3][6] jerk gradient, derivative space
   R *csm = Gs + 18 * MS;     // [MS][3]    jerk cost per (segment, axis)
   R *ccol = csm + 3 * MS;    // [MS]       wc * collision (+dyn) cost per segment
-  R *gseg = coef;            // [MS][3][6] derivative-space gradient per segment (phase 3 on; coef is dead by then)
   R *dts = ccol + MS;        // [MS]       T_s / 30 (:351)
-  R *Gc = dts + MS;          // [MS][3][6] wc * collision gradient, coefficient space
-  R *red = Gc + 18 * MS;     // [NW][kRedChunk][65] per-wave transpose-reduction tile
+  R *iTs = dts + MS;         // [MS]       1 / T_s
+  R *gseg = coef;            // [MS][3][6] total gradient per segment, derivative space [p0,pT,v0,vT,a0,aT];
+                             //            written by a wavefront over ITS segments' coef after its sample loop
+  R *red = iTs + MS;         // [NW][kRedChunk][65] per-wave transpose-reduction tile
   R *myred = red + wave * (kRedChunk * kRedStride);
 
   const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
@@ -429,55 +429,30 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
     GTOP_STAMP(0);
     const int ntraj = min(TPB, a.B - b0);   // trajectories this pass
     const int nseg = ntraj * m;             // live virtual segments
-    // ---- phase 0: stage x, Df, T of the ntraj trajectories in LDS (contiguous in HBM) ----
-    {
-      const R *xb = a.x + (size_t)b0 * n;
-      for (int q = tid; q < ntraj * n; q += nthr) {
-        int tl = 0, i = q;
-        while (i >= n) { i -= n; ++tl; }     // TPB is small
-        const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
-        dv[(tl * 3 + axis) * ND + 6 + c] = xb[q];
-      }
-      const R *dfb = a.Df + (size_t)b0 * 18;
-      for (int q = tid; q < ntraj * 18; q += nthr) {
-        const int tl = q / 18, r = q - tl * 18, axis = r / 6, j = r - axis * 6;
-        dv[(tl * 3 + axis) * ND + j] = dfb[q];
-      }
-      if (a.t_stride) {
-        const R *tb = a.T + (size_t)b0 * m;
-        for (int q = tid; q < nseg; q += nthr) Ts[q] = tb[q];
-      } else {
-        for (int q = tid; q < nseg; q += nthr) {
-          int s = q;
-          while (s >= m) s -= m;
-          Ts[q] = a.T[s];
-        }
-      }
-    }
-    __syncthreads();
-    GTOP_STAMP(1);
-
-    // ---- phase 1: per (segment, axis): coefficients, jerk cost, 2Qc ----
+    // ---- phase 1: per (segment, axis): coefficients, jerk cost and jerk gradient ----
+    // Its 3*m*TPB lanes read their seven inputs (two waypoints' p,v,a and T_s)
+    // straight from HBM/L2 — there is no staging pass: nothing else needs x or Df.
     for (int w = tid; w < 3 * nseg; w += nthr) {
       const int S = w / 3, k = w - 3 * S;
       int tl = 0, s = S;
       while (s >= m) { s -= m; ++tl; }
-      const R *d = dv + (tl * 3 + k) * ND;
-      // global derivative vector layout (src/qp_generator.cpp:363-387):
-      // [start p,v,a | end p,v,a | waypoint 1 p,v,a | ... | waypoint m-1 p,v,a]
-      const int o0 = (s == 0) ? 0 : 6 + 3 * (s - 1);
-      const int o1 = (s + 1 == m) ? 3 : 6 + 3 * s;
-      const R p0 = d[o0], v0 = d[o0 + 1], a0 = d[o0 + 2];
-      const R pT = d[o1], vT = d[o1 + 1], aT = d[o1 + 2];
-      const R T = Ts[S], T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
-      const R iT = fast_rcp(T), iT3 = iT * iT * iT;
+      const R *xk = a.x + (size_t)(b0 + tl) * n + k * ndp;    // free variables of axis k (:182-187)
+      const R *df = a.Df + (size_t)(b0 + tl) * 18 + k * 6;    // [p,v,a]_start, [p,v,a]_end
+      // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
+      const R *w0 = (s == 0) ? df : xk + 3 * (s - 1);
+      const R *w1 = (s + 1 == m) ? df + 3 : xk + 3 * s;
+      const R p0 = w0[0], v0 = w0[1], a0 = w0[2];
+      const R pT = w1[0], vT = w1[1], aT = w1[2];
+      const R T = a.T[(size_t)(b0 + tl) * a.t_stride + s];
+      const R T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+      const R iT = fast_rcp(T), iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
       // closed-form A_s^-1 (rows of A_s: src/qp_generator.cpp:185-195)
       const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
       const R V = (vT - v0 - a0 * T) * T;
       const R A = (aT - a0) * T2;
       const R c3 = ((R)10 * P - (R)4 * V + (R)0.5 * A) * iT3;
-      const R c4 = ((R)-15 * P + (R)7 * V - A) * (iT3 * iT);
-      const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) * (iT3 * iT * iT);
+      const R c4 = ((R)-15 * P + (R)7 * V - A) * iT4;
+      const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) * iT5;
       R *cf = coef + w * 6;
       cf[0] = p0; cf[1] = v0; cf[2] = (R)0.5 * a0; cf[3] = c3; cf[4] = c4; cf[5] = c5;
       // jerk Hessian Q_s (src/qp_generator.cpp:226-234): i,j in {3,4,5}
@@ -485,32 +460,45 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
       const R q4 = (R)72 * T2 * c3 + (R)192 * T3 * c4 + (R)360 * T4 * c5;
       const R q5 = (R)120 * T3 * c3 + (R)360 * T4 * c4 + (R)720 * T5 * c5;
       csm[w] = c3 * q3 + c4 * q4 + c5 * q5;   // c'Qc  == this (s,k)'s share of d'Rd (:326-327)
-      R *g = Gs + w * 6;                      // ws * 2Qc == share of ws*(2Rfp'df + 2Rpp dp) (:330-336)
-      g[0] = (R)0; g[1] = (R)0; g[2] = (R)0;
-      g[3] = ws * (R)2 * q3; g[4] = ws * (R)2 * q4; g[5] = ws * (R)2 * q5;
-    }
-    // sample times.  The reference's `for (t = 1e-3; t < T; t += dt)` (:353)
-    // accumulates t by repeated addition.  For T >= 0.0301 all 30 samples pass
-    // the loop test whatever the rounding, and t_i = 1e-3 + i*dt differs from the
-    // accumulated value by a few ulp (1e-15 relative, far inside the 1e-5
-    // budget), so lanes form it with one fma.  Below that the
-    // sample COUNT depends on the accumulated value (29 at T = 0.03, fewer for
-    // tinier T), so for those segments each lane replays the addition chain.
-    for (int S = (int)nthr - 1 - tid; S < nseg; S += nthr) {   // highest lanes: the ones idle above
-      const R Tv = Ts[S];
-      const R dt = Tv / (R)30.0;                // :351
-      dts[S] = dt;
-      ccol[S] = (R)0;
+      // ws * 2Qc == share of ws*(2Rfp'df + 2Rpp dp) (:330-336), taken to derivative
+      // space [p0,pT,v0,vT,a0,aT] by A_s^-T right away (its coefficient-space
+      // entries 0..2 are zero)
+      const R H3 = ws * (R)2 * q3 * iT3, H4 = ws * (R)2 * q4 * iT4, H5 = ws * (R)2 * q5 * iT5;
+      const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
+      R *g = Gs + w * 6;
+      g[0] = -ap;
+      g[1] = ap;
+      g[2] = T * ((R)-6 * H3 + (R)8 * H4 - (R)3 * H5);
+      g[3] = T * ((R)-4 * H3 + (R)7 * H4 - (R)3 * H5);
+      g[4] = T2 * ((R)-1.5 * H3 + (R)1.5 * H4 - (R)0.5 * H5);
+      g[5] = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
+      if (k == 0) {
+        Ts[S] = T;
+        iTs[S] = iT;
+        dts[S] = T / (R)30.0;   // :351
+        ccol[S] = (R)0;
+      }
     }
     __syncthreads();
+    GTOP_STAMP(1);
     GTOP_STAMP(2);
 
+    // Sample times: the reference's `for (t = 1e-3; t < T; t += dt)` (:353)
+    // accumulates t by repeated addition.  For T >= 0.0301 all 30 samples pass the
+    // loop test whatever the rounding, and t_i = 1e-3 + i*dt differs from the
+    // accumulated value by a few ulp (1e-15 relative, far inside the 1e-5 budget;
+    // SURVEY A.4 Q8), so lanes form it with one fma.  Below that the sample COUNT
+    // depends on the accumulated value (29 at T = 0.03, fewer for tinier T), so for
+    // those segments each lane replays the addition chain.
     // ---- phase 2: collision samples (:345-409) ----
     if (do_colli) {
       for (int s0 = 0; s0 < nseg; s0 += SPW * NW) {   // block-uniform trip count
         const int S = s0 + wave * SPW + slot;
         const bool seg_ok = (slot < SPW) & (S < nseg);
-        const int sc = seg_ok ? S : 0;             // clamped: inactive lanes compute on segment 0, then discard
+        // idle lanes shadow a live segment (their own wavefront's first one when it has
+        // any) so that they compute on finite data; their results are never read
+        const int s_first = s0 + wave * SPW;
+        const int sc = seg_ok ? S : (s_first < nseg ? s_first : 0);
         R acc[kRedVals];
 #pragma unroll
         for (int v = 0; v < kRedVals; ++v) acc[v] = (R)0;
@@ -643,6 +631,25 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
           if constexpr (SPL == 1) acc[18] = csum;
           else acc[18] += csum;
         }
+        // A_s^-T on this lane's 18 accumulators (coefficient space -> [p0,pT,v0,vT,a0,aT]
+        // per axis), so that the reduction below already yields what the free
+        // variables gather; the map is linear, so it commutes with the sums.
+        {
+          const R T = Tseg, T2 = T * T, iT = iTs[sc];
+          const R iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            R *g = acc + 6 * k;
+            const R H3 = g[3] * iT3, H4 = g[4] * iT4, H5 = g[5] * iT5;
+            const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
+            const R o0 = g[0] - ap;
+            const R o2 = g[1] + T * ((R)-6 * H3 + (R)8 * H4 - (R)3 * H5);
+            const R o3 = T * ((R)-4 * H3 + (R)7 * H4 - (R)3 * H5);
+            const R o4 = (R)0.5 * g[2] + T2 * ((R)-1.5 * H3 + (R)1.5 * H4 - (R)0.5 * H5);
+            const R o5 = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
+            g[0] = o0; g[1] = ap; g[2] = o2; g[3] = o3; g[4] = o4; g[5] = o5;
+          }
+        }
 #ifdef GTOP_STAMPS   // pin the sample arithmetic in front of the stamp
         asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[11]), "v"(acc[17]), "v"(acc[18]));
 #endif
@@ -651,7 +658,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
           // one lane owns the whole segment: no cross-lane reduction
           if (seg_ok) {
 #pragma unroll
-            for (int v = 0; v < 18; ++v) Gc[S * 18 + v] = acc[v];
+            for (int v = 0; v < 18; ++v) gseg[S * 18 + v] = Gs[S * 18 + v] + acc[v];
             ccol[S] = acc[18];
           }
         } else {
@@ -676,9 +683,11 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
             for (int u = 0; u < kRdr; ++u) {
               const int r = lane + 64 * u;
               const int rs = r / cn, v = r - rs * cn;   // (segment slot, value in chunk)
-              const bool ok = (r < SPW * cn) & (s0 + wave * SPW + rs < nseg);
+              const int Sr = s0 + wave * SPW + rs;
+              const bool ok = (r < SPW * cn) & (Sr < nseg);
               const R *col = myred + (ok ? v * kRedStride + rs * LPS : 0);
-              sums[u] = tree_sum<R, LPS>(col);
+              const R jerk = (ok & (c0 + v < 18)) ? Gs[Sr * 18 + c0 + v] : (R)0;
+              sums[u] = jerk + tree_sum<R, LPS>(col);
             }
 #pragma unroll
             for (int u = 0; u < kRdr; ++u) {
@@ -686,7 +695,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
               const int rs = r / cn, v = r - rs * cn;
               const int Sr = s0 + wave * SPW + rs;
               if ((r < SPW * cn) & (Sr < nseg)) {
-                if (c0 + v < 18) Gc[Sr * 18 + c0 + v] = sums[u];
+                if (c0 + v < 18) gseg[Sr * 18 + c0 + v] = sums[u];
                 else ccol[Sr] = sums[u];
               }
             }
@@ -696,30 +705,11 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
         }
       }
     } else {
-      for (int q = tid; q < 18 * nseg; q += nthr) Gc[q] = (R)0;   // |wc| < 1e-4: no collision term (:346)
+      for (int q = tid; q < 18 * nseg; q += nthr) gseg[q] = Gs[q];   // |wc| < 1e-4: no collision term (:346)
     }
-    __syncthreads();   // Gc / ccol of every wavefront are complete
+    __syncthreads();   // gseg / ccol of every wavefront are complete
     GTOP_STAMP(4);
 
-    // ---- phase 3: coefficient space -> derivative space (A_s^-T) ----
-    for (int w = tid; w < 3 * nseg; w += nthr) {
-      const int S = w / 3;
-      R g[6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) g[j] = Gs[w * 6 + j] + Gc[w * 6 + j];
-      const R T = Ts[S], T2 = T * T;
-      const R iT = fast_rcp(T), iT3 = iT * iT * iT;
-      const R H3 = g[3] * iT3, H4 = g[4] * (iT3 * iT), H5 = g[5] * (iT3 * iT * iT);
-      const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
-      R *o = gseg + w * 6;   // [p0, pT, v0, vT, a0, aT]
-      o[0] = g[0] - ap;
-      o[1] = ap;
-      o[2] = g[1] + T * ((R)-6 * H3 + (R)8 * H4 - (R)3 * H5);
-      o[3] = T * ((R)-4 * H3 + (R)7 * H4 - (R)3 * H5);
-      o[4] = (R)0.5 * g[2] + T2 * ((R)-1.5 * H3 + (R)1.5 * H4 - (R)0.5 * H5);
-      o[5] = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
-    }
-    __syncthreads();
     GTOP_STAMP(5);
 
     // ---- phase 4: gather to the free variables, +1e-5 (:425-432); cost (:417-418) ----
@@ -762,8 +752,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
 }  // namespace
 
 size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem) {
-  const size_t ND = 3 * (size_t)m + 3, MS = (size_t)tpb * m;
-  size_t elems = 3 * ND * tpb + MS + 18 * MS * 2 + 3 * MS + MS + MS + 18 * MS +
+  const size_t MS = (size_t)tpb * m;
+  size_t elems = MS + 18 * MS * 2 + 3 * MS + MS + MS + MS +
                  (size_t)waves * kRedChunk * kRedStride;
   return elems * elem;
 }
@@ -826,6 +816,12 @@ hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMm
   return dyn ? launch_spl<double, true, true>(args, st, waves, spl, grid, smem, stream)
              : launch_spl<double, false, true>(args, st, waves, spl, grid, smem, stream);
 }
+
+#ifdef GTOP_STAMPS
+extern "C" int gtop_debug_read_stamps(unsigned long long *out /*4096*8*/) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gtop_stamps), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
 
 template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, int, bool, int, hipStream_t);
 template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, int, bool, int, hipStream_t);
