@@ -54,6 +54,7 @@ struct gtop_ctx {
   int waves = 0;   // 0 = auto
   int spl = 0;     // samples per lane, 0 = auto
   bool fuse_mma = true;     // optimizer: MMA update fused into the evaluation kernel (tuning/debug knob)
+  int auto_spl_small = 3;   // what auto picks for B < 4096 (m = 6: one wavefront per trajectory)
   int auto_spl_large = 6;   // what auto picks for B >= 4096 (m = 6: two trajectories per wavefront)
 
   // bookkeeping of the callback (grad_traj_optimizer.cpp:284, :436, :439-447)
@@ -140,13 +141,13 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
 // Launch geometry.  spl (samples per lane, a divisor of 30) sets how many
 // segments one wavefront holds (spw = 2, 4, 6, 10, 12, 21, 32, 64 for spl =
 // 1, 2, 3, 5, 6, 10, 15, 30); a workgroup of `waves` wavefronts then owns
-// tpb = floor(waves*spw / m) whole trajectories (at least 1).  Auto: large
-// batches are throughput-bound -> several trajectories per wavefront, which
-// amortises the few-lane phases; small batches are latency-bound -> spread one
-// trajectory over more wavefronts.
+// tpb = floor(waves*spw / m) whole trajectories (at least 1).  Auto (measured,
+// profiles/r1/sweep_geometry_v4.txt): B >= 4096 -> spl 6 (two 20-control-point
+// trajectories per wavefront, amortising the few-lane phases); smaller batches
+// -> spl 3 (one wavefront per trajectory: more wavefronts in flight).
 void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb) {
   int s = c->spl;
-  if (s == 0) s = (B >= 4096) ? c->auto_spl_large : 1;
+  if (s == 0) s = (B >= 4096) ? c->auto_spl_large : c->auto_spl_small;
   const int spw = gtop_eval_segments_per_wave(s);
   int w = c->waves > 0 ? c->waves : (spw >= m ? 1 : (m + spw - 1) / spw);
   if (w < 1) w = 1;
@@ -590,7 +591,7 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
   HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
   int waves, spl, tpb;
   launch_geometry(c, B, m, &waves, &spl, &tpb);
-  const bool fused = c->fuse_mma && (spl == 1 || spl == 6);
+  const bool fused = c->fuse_mma && (spl == 1 || spl == 3 || spl == 6);
   for (int it = 0; it < max_evals; ++it) {
     if (fused) {
       // one launch per iteration: the evaluation kernel runs the MMA update as its epilogue

@@ -70,7 +70,7 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, double 
                                   double *dist, int *vws, double *zws, size_t ws_lines,
                                   hipStream_t stream);
 
-// fused: cost/gradient at st.xcur + MMA update in one launch (fp64; spl must be 1 or 6)
+// fused: cost/gradient at st.xcur + MMA update in one launch (fp64; spl must be 1, 3 or 6)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
                                 bool dyn, int max_blocks, hipStream_t stream);
 hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const double *x0, hipStream_t stream);

@@ -37,6 +37,9 @@ namespace {
 #ifndef GTOP_SAMPLE_UNROLL
 #define GTOP_SAMPLE_UNROLL 1     // unroll factor of the per-lane sample loop (tuning knob)
 #endif
+#ifndef GTOP_F64_MIN_WAVES
+#define GTOP_F64_MIN_WAVES 2
+#endif
 #ifndef GTOP_F32_MIN_WAVES
 #define GTOP_F32_MIN_WAVES 3
 #endif
@@ -378,7 +381,7 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
 //   SPL = 15, NW = 1, TPB = 5: 2 lanes per segment, 5 trajectories per wavefront
 // Register budget: the fp32 bodies fit 128 VGPRs (4 waves per SIMD) with at most
 // a couple of spilled dwords; the fp64 bodies need their ~190.
-template <typename R> struct MinWaves { static constexpr int v = 2; };
+template <typename R> struct MinWaves { static constexpr int v = GTOP_F64_MIN_WAVES; };
 template <> struct MinWaves<float> { static constexpr int v = GTOP_F32_MIN_WAVES; };
 
 //
@@ -767,6 +770,7 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
   if constexpr (MMA) {   // the fused optimizer step is built for the two geometries the auto rule picks
     switch (spl) {
       case 1: kern = gtop_eval_kernel<R, DYN, 1, true>; break;
+      case 3: kern = gtop_eval_kernel<R, DYN, 3, true>; break;
       case 6: kern = gtop_eval_kernel<R, DYN, 6, true>; break;
       default: return hipErrorInvalidValue;
     }
@@ -805,7 +809,7 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, b
              : launch_spl<R, false, false>(args, none, waves, spl, grid, smem, stream);
 }
 
-// cost/gradient at st.xcur + the MMA update, one launch (fp64; spl 1 or 6)
+// cost/gradient at st.xcur + the MMA update, one launch (fp64; spl 1, 3 or 6)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
                                 bool dyn, int max_blocks, hipStream_t stream) {
   if (args.B <= 0) return hipSuccess;
