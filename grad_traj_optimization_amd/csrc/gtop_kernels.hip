@@ -37,6 +37,9 @@ namespace {
 #ifndef GTOP_SAMPLE_UNROLL
 #define GTOP_SAMPLE_UNROLL 1     // unroll factor of the per-lane sample loop (tuning knob)
 #endif
+#ifndef GTOP_MAX_THREADS
+#define GTOP_MAX_THREADS 512
+#endif
 #ifndef GTOP_F64_MIN_WAVES
 #define GTOP_F64_MIN_WAVES 2
 #endif
@@ -390,7 +393,7 @@ template <> struct MinWaves<float> { static constexpr int v = GTOP_F32_MIN_WAVES
 // a trajectory are known the same workgroup runs its MMA update
 // (gtop_mma_update_trajectory) — one launch per optimizer iteration.
 template <typename R, bool DYN, int SPL, bool MMA>
-__global__ void __launch_bounds__(512, (MinWaves<R>::v)) GTOP_WAVES_PER_EU_ATTR
+__global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R>::v)) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront
