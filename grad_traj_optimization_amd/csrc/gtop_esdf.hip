@@ -1,22 +1,38 @@
 // gtop_esdf.hip — Euclidean distance field construction on gfx950.
 //
 // Replaces SDFMap::resetBuffer / setOccupancy / updateESDF3d
-// (src/sdf_map.cpp:26-53, :80-99, :310-368 of EpicOne1/grad_traj_optimization):
-// three 1-D lower-envelope (Felzenszwalb–Huttenlocher) sweeps, z then y then x,
-// then dist = min(res*sqrt(val), previous).  Integer/byte work plus exactly
-// rounded fp64 (+, -, /, sqrt), so the result is bit-identical to the CPU
-// restatement.  HBM-bound: one lane per grid line; in the y and x sweeps
-// neighbouring lanes walk neighbouring z columns, so every step of the sweep
-// is a coalesced row; the per-line envelope scratch is laid out [k][line] for
-// the same reason.
+// (src/sdf_map.cpp:26-53, :80-99, :310-368 of EpicOne1/grad_traj_optimization).
+// The reference runs three 1-D lower-envelope (Felzenszwalb–Huttenlocher)
+// sweeps, z then y then x, over doubles with DBL_MAX as "no obstacle", then
+// dist = min(res*sqrt(val), previous).  Each sweep computes, per line,
+//     out(q) = min_v ( (q - v)^2 + in(v) )
+// and on this data every quantity is an exact integer (squared voxel
+// distances; the envelope's intersection abscissae are ratios of small
+// integers, so their rounding cannot flip a comparison), i.e. the sweep output
+// IS that exact minimum.  The kernels below compute the same minimum directly,
+// one lane per voxel, in int32 with an INF sentinel:
+//   z sweep : the input is the occupancy itself, so out(q) = (distance to the
+//             nearest occupied voxel of the column)^2 — found with wave
+//             ballots (one 64-bit mask per 64 voxels of the column) and
+//             clz/ctz, no search loop;
+//   y, x    : outward scan v = q, q±1, q±2, ... with the exact cut-off
+//             d^2 >= best (in(v) >= 0), neighbouring lanes on neighbouring z
+//             so every step is a coalesced row;
+//   x sweep : also the final res*sqrt(.) (exactly rounded fp64, as the
+//             reference's) and the fp32 copy used by the GTOP_F32 path.
+// Result: bit-identical to the CPU restatement and to scipy's exact EDT
+// (tests), HBM/latency-bound integer work, no scratch workspace.  (An LDS-tiled
+// variant of the y/x scans was measured 4-6x SLOWER: 3 200 long-running
+// wavefronts instead of 125 000 short ones; profiles/r1/esdf_kernels.txt.)
 
 #include <hip/hip_runtime.h>
-#include <float.h>
 #include <stdint.h>
 
 #include "gtop_kernels.h"
 
 namespace {
+
+constexpr int kInf = 0x3fffffff;   // "no obstacle on this line so far"; d^2 + kInf stays below 2^31 for lines <= 2^15
 
 __global__ void __launch_bounds__(256)
 esdf_reset_kernel(uint8_t *__restrict__ occ, double *__restrict__ dist, size_t nvox) {
@@ -45,77 +61,94 @@ esdf_mark_kernel(const GtopGrid g, const double *__restrict__ pts, int npts,
   occ[((size_t)ix * g.ny + iy) * g.nz + iz] = 1;   // sdf_map.cpp:97-98
 }
 
-// One lane per line.  PASS 0: z sweep reading occupancy; 1: y sweep; 2: x sweep
-// with the final min(res*sqrt(.), old) (sdf_map.cpp:355-361).
-// fillESDF, sdf_map.cpp:266-308, with start = 0, end = n-1.
+// z sweep (sdf_map.cpp:311-326): one wavefront per (x,y) column.
+constexpr int kMaxChunks = 64;   // columns up to 4096 voxels
+
+__global__ void __launch_bounds__(256)
+esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out) {
+  __shared__ unsigned long long masks[4][kMaxChunks];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t ncol = (size_t)g.nx * g.ny;
+  const int nz = g.nz, nchunk = (nz + 63) >> 6;
+  for (size_t col = (size_t)blockIdx.x * 4 + w; col < ncol; col += (size_t)gridDim.x * 4) {
+    const uint8_t *c = occ + col * nz;
+    for (int k = 0; k < nchunk; ++k) {
+      const int z = k * 64 + lane;
+      const bool o = (z < nz) && (c[z] == 1);
+      const unsigned long long mk = __ballot(o);
+      if (lane == 0) masks[w][k] = mk;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int ko = 0; ko < nchunk; ++ko) {
+      const int z = ko * 64 + lane;
+      int best = kInf;   // distance in voxels to the nearest occupied voxel of the column
+      for (int k = 0; k < nchunk; ++k) {
+        const unsigned long long mk = masks[w][k];
+        if (mk == 0) continue;   // wave-uniform
+        int d;
+        if (k < ko) {
+          d = z - (k * 64 + 63 - __clzll((long long)mk));        // its highest occupied voxel
+        } else if (k > ko) {
+          d = k * 64 + (__ffsll((long long)mk) - 1) - z;          // its lowest occupied voxel
+        } else {
+          const unsigned long long below = mk & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));   // bits <= lane
+          const unsigned long long above = mk & (~0ull << lane);                                     // bits >= lane
+          const int d1 = below ? lane - (63 - __clzll((long long)below)) : kInf;
+          const int d2 = above ? (__ffsll((long long)above) - 1) - lane : kInf;
+          d = d1 < d2 ? d1 : d2;
+        }
+        best = d < best ? d : best;
+      }
+      if (z < nz) out[col * nz + z] = best >= kInf ? kInf : best * best;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// y sweep (PASS 1, sdf_map.cpp:328-346) and x sweep (PASS 2, :348-364): one lane
+// per voxel, lanes along z.  out(q) = min_v ((q-v)^2 + in(v)), scanning outward.
 template <int PASS>
 __global__ void __launch_bounds__(256)
-esdf_sweep_kernel(const GtopGrid g, const uint8_t *__restrict__ occ,
-                  const double *__restrict__ fin, double *__restrict__ fout,
-                  int *__restrict__ vws, double *__restrict__ zws,
-                  size_t line0, size_t nlines_chunk, size_t ws_lines) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nlines_chunk) return;
-  const size_t line = line0 + t;
+esdf_scan_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ fout,
+                 double *__restrict__ dist, float *__restrict__ dist32) {
+  const size_t nvox = (size_t)g.nx * g.ny * g.nz;
   const size_t nyz = (size_t)g.ny * g.nz;
-  size_t base, stride;
-  int n;
-  if (PASS == 0) {          // line = x*ny + y
-    base = line * g.nz; stride = 1; n = g.nz;
-  } else if (PASS == 1) {   // line = x*nz + z
-    const size_t x = line / g.nz, z = line - x * g.nz;
-    base = x * nyz + z; stride = g.nz; n = g.ny;
-  } else {                  // line = y*nz + z
-    base = line; stride = nyz; n = g.nx;
-  }
-  auto f = [&](int q) -> double {
-    if (PASS == 0) return occ[base + (size_t)q * stride] == 1 ? 0.0 : DBL_MAX;  // :314-318
-    return fin[base + (size_t)q * stride];
-  };
-  // scratch: v[k], z[k] at [k*ws_lines + t]
-  auto V = [&](int k) -> int & { return vws[(size_t)k * ws_lines + t]; };
-  auto Z = [&](int k) -> double & { return zws[(size_t)k * ws_lines + t]; };
-
-  int k = 0;
-  V(0) = 0;
-  Z(0) = -DBL_MAX;
-  Z(1) = DBL_MAX;
-  int vk = 0;            // v[k] kept in a register
-  double fvk = f(0);     // f(v[k])
-  for (int q = 1; q < n; q++) {
-    const double fq = f(q);
-    double s;
-    k++;
-    do {
-      k--;
-      vk = V(k);
-      fvk = f(vk);
-      s = ((fq + q * q) - (fvk + vk * vk)) / (2 * q - 2 * vk);
-    } while (s <= Z(k));
-    k++;
-    V(k) = q;
-    Z(k) = s;
-    Z(k + 1) = DBL_MAX;
-  }
-  k = 0;
-  vk = V(0);
-  fvk = f(vk);
-  double znext = Z(1);
-  for (int q = 0; q < n; q++) {
-    while (znext < q) {
-      k++;
-      vk = V(k);
-      fvk = f(vk);
-      znext = Z(k + 1);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i / nyz);
+    const size_t r = i - (size_t)x * nyz;
+    const int y = (int)(r / g.nz);
+    const int q = PASS == 1 ? y : x;
+    const int n = PASS == 1 ? g.ny : g.nx;
+    const size_t stride = PASS == 1 ? (size_t)g.nz : nyz;
+    const int *line = fin + (i - (size_t)q * stride);
+    int best = line[(size_t)q * stride];
+    const int reach = q > n - 1 - q ? q : n - 1 - q;
+    for (int d = 1; d <= reach; ++d) {
+      const int dd = d * d;
+      if (dd >= best) break;   // in(v) >= 0: nothing farther can win
+      if (q - d >= 0) {
+        const int c = dd + line[(size_t)(q - d) * stride];
+        best = c < best ? c : best;
+      }
+      if (q + d < n) {
+        const int c = dd + line[(size_t)(q + d) * stride];
+        best = c < best ? c : best;
+      }
     }
-    const double val = (q - vk) * (q - vk) + fvk;
-    const size_t o = base + (size_t)q * stride;
-    if (PASS == 2) {
-      const double d = g.res * sqrt(val);
-      const double old = fout[o];
-      fout[o] = d < old ? d : old;
+    if (best > kInf) best = kInf;
+    if (PASS == 1) {
+      fout[i] = best;
     } else {
-      fout[o] = val;
+      // sdf_map.cpp:355-361: min(res*sqrt(val), previous) with previous = 10000 after the
+      // reset; a line without obstacles carries DBL_MAX there, i.e. keeps the 10000
+      double dv = 10000.0;
+      if (best < kInf) {
+        const double e = g.res * sqrt((double)best);
+        dv = e < dv ? e : dv;
+      }
+      dist[i] = dv;
+      dist32[i] = (float)dv;
     }
   }
 }
@@ -134,34 +167,23 @@ hipError_t gtop_launch_esdf_mark(const GtopGrid &g, const double *pts, int npts,
   return hipGetLastError();
 }
 
-size_t gtop_esdf_ws_lines(const GtopGrid &g) {
-  size_t l0 = (size_t)g.nx * g.ny, l1 = (size_t)g.nx * g.nz, l2 = (size_t)g.ny * g.nz;
-  size_t mx = l0 > l1 ? l0 : l1;
-  mx = mx > l2 ? mx : l2;
-  const size_t cap = 65536;   // lines processed per launch
-  return mx < cap ? mx : cap;
+bool gtop_esdf_supported(const GtopGrid &g) {
+  return g.nz <= 64 * kMaxChunks && g.nx <= 32768 && g.ny <= 32768;
 }
 
-hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, double *tmp1, double *tmp2,
-                                  double *dist, int *vws, double *zws, size_t ws_lines,
-                                  hipStream_t stream) {
-  const size_t lines[3] = {(size_t)g.nx * g.ny, (size_t)g.nx * g.nz, (size_t)g.ny * g.nz};
-  for (int pass = 0; pass < 3; ++pass) {
-    for (size_t l0 = 0; l0 < lines[pass]; l0 += ws_lines) {
-      const size_t nl = lines[pass] - l0 < ws_lines ? lines[pass] - l0 : ws_lines;
-      const dim3 grid((unsigned)((nl + 255) / 256)), block(256);
-      if (pass == 0)
-        hipLaunchKernelGGL(esdf_sweep_kernel<0>, grid, block, 0, stream, g, occ, (const double *)nullptr,
-                           tmp1, vws, zws, l0, nl, ws_lines);
-      else if (pass == 1)
-        hipLaunchKernelGGL(esdf_sweep_kernel<1>, grid, block, 0, stream, g, occ, (const double *)tmp1,
-                           tmp2, vws, zws, l0, nl, ws_lines);
-      else
-        hipLaunchKernelGGL(esdf_sweep_kernel<2>, grid, block, 0, stream, g, occ, (const double *)tmp2,
-                           dist, vws, zws, l0, nl, ws_lines);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) return e;
-    }
-  }
-  return hipSuccess;
+hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, double *dist,
+                                  float *dist32, hipStream_t stream) {
+  const size_t ncol = (size_t)g.nx * g.ny, nvox = ncol * g.nz;
+  const unsigned zblocks = (unsigned)((ncol + 3) / 4 < 65536 ? (ncol + 3) / 4 : 65536);
+  hipLaunchKernelGGL(esdf_z_kernel, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const unsigned vblocks = (unsigned)((nvox + 255) / 256 < (1u << 20) ? (nvox + 255) / 256 : (1u << 20));
+  hipLaunchKernelGGL(esdf_scan_kernel<1>, dim3(vblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2,
+                     (double *)nullptr, (float *)nullptr);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(esdf_scan_kernel<2>, dim3(vblocks), dim3(256), 0, stream, g, (const int *)tmp2, (int *)nullptr,
+                     dist, dist32);
+  return hipGetLastError();
 }

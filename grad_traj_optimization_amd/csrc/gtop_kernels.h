@@ -63,12 +63,11 @@ hipError_t gtop_launch_esdf_reset(uint8_t *occ, double *dist, size_t nvox, hipSt
 // setOccupancy per point (sdf_map.cpp:80-99)
 hipError_t gtop_launch_esdf_mark(const GtopGrid &g, const double *pts, int npts, uint8_t *occ,
                                  hipStream_t stream);
-// updateESDF3d (sdf_map.cpp:310-368): three 1-D lower-envelope sweeps.
-// tmp1/tmp2: nvox doubles each; vws/zws: per-line scratch for `ws_lines` lines.
-size_t gtop_esdf_ws_lines(const GtopGrid &g);
-hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, double *tmp1, double *tmp2,
-                                  double *dist, int *vws, double *zws, size_t ws_lines,
-                                  hipStream_t stream);
+// updateESDF3d (sdf_map.cpp:310-368): the three sweeps z, y, x as exact integer minimisations,
+// then res*sqrt(.) into dist (fp64) and dist32 (fp32 copy).  tmp1/tmp2: nvox int32 each.
+bool gtop_esdf_supported(const GtopGrid &g);
+hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, double *dist,
+                                  float *dist32, hipStream_t stream);
 
 // fused: cost/gradient at st.xcur + MMA update in one launch (fp64; spl must be 1, 3 or 6)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
