@@ -18,6 +18,7 @@
  * All citations are file:line into /root/reference/.
  * Matrices are dense row-major doubles.
  */
+#define _POSIX_C_SOURCE 200809L
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>

@@ -178,3 +178,15 @@ def test_batch_driver_matches_single_calls(oracle_mod):
     Df0, Dp0 = oracle_mod.initial_d(b.waypoints[0])
     Dfp, Dpp = problem.initial_derivatives(b.waypoints[:1])
     assert np.array_equal(Df0, Dfp[0]) and np.array_equal(Dp0, Dpp[0])
+
+
+def test_restatement_is_sanitizer_clean():
+    """ASan + UBSan build of the C restatement over every entry point (CPU only)."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", here, "-s", "_build/oracle_asan"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    out = subprocess.run([os.path.join(here, "_build", "oracle_asan")], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0 and "oracle_asan: ok" in out.stdout, out.stdout + out.stderr
