@@ -281,3 +281,43 @@ def test_full_size_400_cube_m12(gtop, oracle_mod):
     c_ref, g_ref, _ = oracle_mod.eval_batch(b.T[idx], b.Df[idx], b.x[idx], sdf, oracle_mod.make_params(), nthreads=8)
     rc, rg = scenes.rel_err(c[idx].cpu().numpy(), g[idx].cpu().numpy(), c_ref, g_ref)
     assert rc <= TOL64 and rg <= TOL64, (rc, rg)
+
+
+def test_borrowed_device_field(scene, oracle_mod, gtop):
+    """gtop_set_sdf_device: a distance field that already lives in HBM (fp64 or fp32) is
+    used in place, not copied; the other precision is then unavailable (GTOP_ERR_STATE)."""
+    import torch
+    mp, ctx0, sdf = scene
+    dev = torch.device("cuda:0")
+    b = problem.make_trajectories(32, 6, mp, seed=21)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params())
+    for td, tol in ((torch.float64, TOL64), (torch.float32, TOL32)):
+        field = torch.tensor(sdf.dist.reshape(mp.grid), dtype=td, device=dev).contiguous()
+        ctx = gtop.GtopContext(device=0)
+        ctx.set_sdf_device(field, mp.grid, mp.origin, mp.resolution, map_size=mp.map_size)
+        x = torch.tensor(b.x, dtype=td, device=dev)
+        Df = torch.tensor(b.Df.reshape(-1, 18), dtype=td, device=dev)
+        T = torch.tensor(b.T, dtype=td, device=dev)
+        c, g = ctx.eval_device(x, Df, T)
+        torch.cuda.synchronize()
+        rc, rg = scenes.rel_err(c.double().cpu().numpy(), g.double().cpu().numpy(), c_ref, g_ref)
+        assert rc <= tol and rg <= tol, (td, rc, rg)
+        other = torch.float32 if td == torch.float64 else torch.float64
+        with pytest.raises(gtop.GtopError) as e:
+            ctx.eval_device(x.to(other), Df.to(other), T.to(other))
+        assert e.value.code == 4
+
+
+def test_spatial_order_is_a_pure_permutation(scene, gtop):
+    """Morton ordering of a batch (L2 locality) must not change any result."""
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(500, 6, mp, seed=22)
+    perm = problem.spatial_order(b.waypoints, mp.origin, mp.map_size)
+    assert sorted(perm.tolist()) == list(range(500))
+    ctx.set_params()
+    ctx.set_problem(b.T, b.Df)
+    c, g = ctx.eval_batch(b.x)
+    bp = problem.permute(b, perm)
+    ctx.set_problem(bp.T, bp.Df)
+    cp, gp = ctx.eval_batch(bp.x)
+    assert np.array_equal(cp, c[perm]) and np.array_equal(gp, g[perm])
