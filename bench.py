@@ -284,9 +284,15 @@ def main():
             "esdf_build_s": esdf_s,
         }
         if world == 1 and not args.no_extras:
-            out["extras"] = extras(args, ctx, batch, mp, x, Df, T, tdtype, dev)
+            try:   # untimed additions must never cost the main line
+                out["extras"] = extras(args, ctx, batch, mp, x, Df, T, tdtype, dev)
+            except Exception as e:
+                out["extras"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, batch, mp, ctx)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, batch, mp, ctx)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
     if world > 1:
