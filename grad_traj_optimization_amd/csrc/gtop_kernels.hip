@@ -54,6 +54,9 @@ namespace {
 constexpr int kSamples = 30;     // src/grad_traj_optimizer.cpp:351
 constexpr int kRedVals = 19;     // 18 gradient entries + 1 cost per sample
 constexpr int kRedStride = 65;   // 64 lanes + 1 pad: conflict-free column reads
+#ifndef GTOP_PREISSUE
+#define GTOP_PREISSUE 0
+#endif
 #ifndef GTOP_RED_CHUNK
 #define GTOP_RED_CHUNK 19
 #endif
@@ -63,7 +66,7 @@ constexpr int kRedChunk = GTOP_RED_CHUNK;   // values per transpose-reduction pa
 // of wave 0 of the first 4096 workgroups, into a buffer of its own that nothing
 // else reads.  Never defined in the shipped library.
 #ifdef GTOP_STAMPS
-__device__ unsigned long long g_gtop_stamps[4096][8];
+__device__ unsigned long long g_gtop_stamps[4096][16];
 #define GTOP_STAMP(i)                                                                          \
   do {                                                                                         \
     unsigned long long t_;                                                                     \
@@ -120,9 +123,26 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return y;
 }
 __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
-template <typename R> __device__ __forceinline__ R gsqrt(R v);
-template <> __device__ __forceinline__ double gsqrt<double>(double v) { return sqrt(v); }
-template <> __device__ __forceinline__ float gsqrt<float>(float v) { return sqrtf(v); }
+template <typename R> __device__ __forceinline__ R gfma(R a, R b, R c);
+template <> __device__ __forceinline__ double gfma<double>(double a, double b, double c) { return fma(a, b, c); }
+template <> __device__ __forceinline__ float gfma<float>(float a, float b, float c) { return fmaf(a, b, c); }
+
+// sqrt of a squared speed (src/grad_traj_optimizer.cpp:358).  fp64: the same
+// v_rsq_f64 + coupled Newton refinement the library routine uses, without its
+// exponent rescaling for arguments below 2^-767: the argument is clamped to
+// 1e-200 instead, which changes nothing that survives the "+ 1e-5" of :358.
+__device__ __forceinline__ double speed_sqrt(double s) {
+  s = fmax(s, 1e-200);
+  const double y = __builtin_amdgcn_rsq(s);
+  double g = s * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, s), h, g);
+  g = fma(fma(-g, g, s), h, g);
+  return g;
+}
+__device__ __forceinline__ float speed_sqrt(float s) { return sqrtf(s); }
 template <typename R> __device__ __forceinline__ R gfloor(R v);
 template <> __device__ __forceinline__ double gfloor<double>(double v) { return floor(v); }
 template <> __device__ __forceinline__ float gfloor<float>(float v) { return floorf(v); }
@@ -140,22 +160,33 @@ __device__ __forceinline__ float round_through_float(float v) { return v; }
 // grad uninitialised there, this build defines it as 0.
 // Branch-free: the corner indices are clamped anyway (:166-174), so the loads
 // are always in bounds and the out-of-map case is a final select.
+// The query is split in two so that a caller can put several lookups in flight
+// before consuming the first: sdf_issue does the index arithmetic and issues the
+// four pair loads, sdf_blend is the trilinear arithmetic on the loaded corners.
+template <typename R> struct SdfTap {
+  Pair<R> p00, p01, p10, p11;   // (D[x][y][zb], D[x][y][zb+1]) for the four (x,y) corners
+  R dx, dy, dze;                // interpolation weights (dz already folded with the z-border clamp)
+  bool out, zflat;              // outside the map; clamped at a z border (zero z-gradient)
+};
+
 template <typename R>
-__device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R pz,
-                                       R &gx, R &gy, R &gz, bool &is_out) {
-  const bool out = (px < a.lo[0]) | (py < a.lo[1]) | (pz < a.lo[2]) |
-                   (px > a.hi[0]) | (py > a.hi[1]) | (pz > a.hi[2]);
+__device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, R px, R py, R pz) {
+  SdfTap<R> tp;
+  tp.out = (px < a.lo[0]) | (py < a.lo[1]) | (pz < a.lo[2]) |
+           (px > a.hi[0]) | (py > a.hi[1]) | (pz > a.hi[2]);
   const R res = a.res, rinv = a.res_inv;
   const R half = (R)0.5 * res;
   // posToIndex(pos - 0.5 res)  (:201-204 -> :71-74)
-  const R fx = gfloor(((px - half) - a.origin[0]) * rinv);
-  const R fy = gfloor(((py - half) - a.origin[1]) * rinv);
-  const R fz = gfloor(((pz - half) - a.origin[2]) * rinv);
+  const R ux = ((px - half) - a.origin[0]) * rinv;
+  const R uy = ((py - half) - a.origin[1]) * rinv;
+  const R uz = ((pz - half) - a.origin[2]) * rinv;
+  const R fx = gfloor(ux), fy = gfloor(uy), fz = gfloor(uz);
   const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-  // indexToPos (:76-78) and diff (:209)
-  const R dx = (px - ((fx + (R)0.5) * res + a.origin[0])) * rinv;
-  const R dy = (py - ((fy + (R)0.5) * res + a.origin[1])) * rinv;
-  const R dz = (pz - ((fz + (R)0.5) * res + a.origin[2])) * rinv;
+  // indexToPos (:76-78) and diff (:209): (pos - centre(idx)) / res is the fractional
+  // part of u (equal up to a few ulp of u, ~1e-14 of a voxel)
+  tp.dx = ux - fx;
+  tp.dy = uy - fy;
+  const R dz = uz - fz;
 
   // per-axis clamp of the 8 corner indices (:166-174).  z is the fastest
   // axis, so the two z-corners of each (x,y) column are one 2-element load;
@@ -167,16 +198,26 @@ __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R
   const bool z_lo = iz < 0, z_hi = iz > nz - 2;
   const R *D = a.sdf;
   const uint32_t row0 = (uint32_t)x0 * ny, row1 = (uint32_t)x1 * ny;
-  const Pair<R> p00 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y0) * nz + zb));
-  const Pair<R> p01 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y1) * nz + zb));
-  const Pair<R> p10 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y0) * nz + zb));
-  const Pair<R> p11 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y1) * nz + zb));
-  // values[x][y][z].  At a z border both z-corners clamp to the same voxel
-  // (:166-174); with the pair (D[zb], D[zb+1]) in hand that is dz := 0
-  // (iz = -1) or dz := 1 (iz = nz-1) and a zero z-gradient.
-  const R dze = z_lo ? (R)0 : (z_hi ? (R)1 : dz);
-  const R v000 = p00.x, v001 = p00.y, v010 = p01.x, v011 = p01.y;
-  const R v100 = p10.x, v101 = p10.y, v110 = p11.x, v111 = p11.y;
+  tp.p00 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y0) * nz + zb));
+  tp.p01 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y1) * nz + zb));
+  tp.p10 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y0) * nz + zb));
+  tp.p11 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y1) * nz + zb));
+  // At a z border both z-corners clamp to the same voxel (:166-174); with the
+  // pair (D[zb], D[zb+1]) in hand that is dz := 0 (iz = -1) or dz := 1
+  // (iz = nz-1) and a zero z-gradient.
+  tp.dze = z_lo ? (R)0 : (z_hi ? (R)1 : dz);
+  tp.zflat = z_lo | z_hi;
+  return tp;
+}
+
+template <typename R>
+__device__ __forceinline__ R sdf_blend(const GtopKernelArgs<R> &a, const SdfTap<R> &tp,
+                                       R &gx, R &gy, R &gz, bool &is_out) {
+  const R rinv = a.res_inv;
+  const R dx = tp.dx, dy = tp.dy, dze = tp.dze;
+  // values[x][y][z]
+  const R v000 = tp.p00.x, v001 = tp.p00.y, v010 = tp.p01.x, v011 = tp.p01.y;
+  const R v100 = tp.p10.x, v101 = tp.p10.y, v110 = tp.p11.x, v111 = tp.p11.y;
 
   const R one = (R)1;
   const R ex = one - dx, ey = one - dy, ez = one - dze;
@@ -194,9 +235,9 @@ __device__ __forceinline__ R sdf_query(const GtopKernelArgs<R> &a, R px, R py, R
   g0 += dze * ey * (v101 - v001);
   g0 += dze * dy * (v111 - v011);
   gx = g0 * rinv;
-  gz = (z_lo | z_hi) ? (R)0 : gzz;
-  is_out = out;
-  return out ? (R)-1 : dist;   // the caller zeroes the gradient's weight when out (grad := 0)
+  gz = tp.zflat ? (R)0 : gzz;
+  is_out = tp.out;
+  return tp.out ? (R)-1 : dist;   // the caller zeroes the gradient's weight when out (grad := 0)
 }
 
 template <typename R>
@@ -397,6 +438,10 @@ __global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R>::v)) GTOP_WAVES
 gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront
+  // up to three samples per lane are unrolled outright (the small-batch geometry: one wavefront per SIMD,
+  // the scheduler interleaves the samples); longer loops stay rolled to hold 2 waves per SIMD
+  constexpr int kUnroll = (SPL <= 3) ? SPL : GTOP_SAMPLE_UNROLL;
+  constexpr int CH = (GTOP_PREISSUE && SPL <= 3) ? SPL : 1;   // distance-field lookups in flight per lane
   static_assert(LPS * SPL == kSamples, "SPL must divide 30");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *sm = reinterpret_cast<R *>(smem_raw);
@@ -512,6 +557,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
         const R dt = dts[sc];
         const R wdt = wc * dt;
         const bool tiny_T = Tseg < (R)0.0301;
+        const bool any_tiny = __ballot(tiny_T) != 0ull;   // scalar: the replay below is skipped by a uniform branch
         int coff = sc * 18;
         if constexpr (kIsF32<R> && (SPL % 2 == 0)) {
           // packed fp32: samples jj and jj+1 of this lane together
@@ -538,36 +584,66 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
 #pragma unroll
           for (int v = 0; v < kRedVals; ++v) acc[v] = (R)(acc2[v].x + acc2[v].y);
         } else
-#pragma unroll GTOP_SAMPLE_UNROLL
-        for (int jj = 0; jj < SPL; ++jj) {
-          // the 18 coefficients are re-read from LDS for every sample (broadcast
-          // reads) instead of living in 36 VGPRs across the loop; the empty asm
-          // keeps the compiler from hoisting them back out.
-          asm volatile("" : "+v"(coff));
-          const R *cq = coef + coff;
-          const int si = li + jj * LPS;                                 // sample index 0..29
-          R t = (R)si * dt + (R)1e-3;
-          if (tiny_T) {   // rare: exact replay of `t += dt`
-            t = (R)1e-3;
-            for (int i = 0; i < si; ++i) t += dt;
-          }
-          const bool live = seg_ok & (t < Tseg);   // the loop condition of :353
-          const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-          R pos[3], vel[3], acc3[3];
+#pragma unroll kUnroll
+        for (int j0 = 0; j0 < SPL; j0 += CH) {
+          // Stage A, CH samples: sample time, position/velocity polynomials, distance-field
+          // index arithmetic and the corner loads.  With CH > 1 (the latency
+          // regime: one wavefront per SIMD, nothing else to hide a miss behind) all
+          // CH lookups are in flight before the first is consumed.
+          R ts[CH], vels[CH][3], accs[CH][3];
+          bool lives[CH];
+          SdfTap<R> taps[CH];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const R *q = cq + 6 * k;
-            // :457-465 / :477-485, same left-to-right sums, then the float round trip
-            pos[k] = round_through_float(q[0] + q[1] * t + q[2] * t2 + q[3] * t3 + q[4] * t4 + q[5] * t5);
-            vel[k] = round_through_float(q[1] + (R)2 * q[2] * t + (R)3 * q[3] * t2 + (R)4 * q[4] * t3 + (R)5 * q[5] * t4);
-            if (DYN)  // :497-502
-              acc3[k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
+          for (int c = 0; c < CH; ++c) {
+            // the 18 coefficients are re-read from LDS for every sample (broadcast
+            // reads) instead of living in 36 VGPRs across the loop; the empty asm
+            // keeps the compiler from hoisting them back out.
+            asm volatile("" : "+v"(coff));
+            const R *cq = coef + coff;
+            const int si = li + (j0 + c) * LPS;                           // sample index 0..29
+            R t = (R)si * dt + (R)1e-3;
+            if (any_tiny) {   // wave-uniform, rare: exact replay of `t += dt`
+              if (tiny_T) {
+                t = (R)1e-3;
+                for (int i = 0; i < si; ++i) t += dt;
+              }
+            }
+            ts[c] = t;
+            lives[c] = seg_ok & (t < Tseg);   // the loop condition of :353
+            const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+            const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;   // d/dt of the powers
+            R pos[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const R *q = cq + 6 * k;
+              // :457-465 / :477-485 (sums in the reference's order), then the float round trip
+              pos[k] = round_through_float(q[0] + q[1] * t + q[2] * t2 + q[3] * t3 + q[4] * t4 + q[5] * t5);
+              vels[c][k] = round_through_float(q[1] + q[2] * d2 + q[3] * d3 + q[4] * d4 + q[5] * d5);
+              if (DYN)  // :497-502
+                accs[c][k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
+            }
+            taps[c] = sdf_issue(a, pos[0], pos[1], pos[2]);   // :363
           }
-          const R vn = gsqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;  // :358
+          if constexpr (CH > 1) __builtin_amdgcn_sched_barrier(0);   // keep every load of stage A above stage B
+#ifdef GTOP_STAMPS
+          if (j0 == 0 && s0 == 0) {
+            GTOP_STAMP(8);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GTOP_STAMP(9);
+          }
+#endif
+          // Stage B: trilinear blend, penalty, accumulation.
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+          const R t = ts[c];
+          const bool live = lives[c];
+          const R *vel = vels[c], *acc3 = accs[c];
+          const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+          const R vn = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;  // :358
           const R ivn = fast_rcp(vn);
           R g3[3];
           bool is_out;
-          const R dist = sdf_query(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2], is_out);  // :363
+          const R dist = sdf_blend(a, taps[c], g3[0], g3[1], g3[2], is_out);
           // samples past the loop bound of :353 and idle lanes contribute nothing:
           // every term below carries a factor e
           const R e = live ? penalty_exp((a.d0 - dist) * a.inv_r) : (R)0;   // exp(-(d - d0)/r)
@@ -612,21 +688,13 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             R *ak = acc + 6 * k;
-            if constexpr (SPL == 1) {   // single sample per lane: assign (saves 19 adds of zero)
-              ak[0] = w1[k];
-              ak[1] = w1[k] * t + w2[k];
-              ak[2] = w1[k] * t2 + w2[k] * d2;
-              ak[3] = w1[k] * t3 + w2[k] * d3;
-              ak[4] = w1[k] * t4 + w2[k] * d4;
-              ak[5] = w1[k] * t5 + w2[k] * d5;
-            } else {
-              ak[0] += w1[k];
-              ak[1] += w1[k] * t + w2[k];
-              ak[2] += w1[k] * t2 + w2[k] * d2;
-              ak[3] += w1[k] * t3 + w2[k] * d3;
-              ak[4] += w1[k] * t4 + w2[k] * d4;
-              ak[5] += w1[k] * t5 + w2[k] * d5;
-            }
+            // two fused multiply-adds per entry
+            ak[0] += w1[k];
+            ak[1] = gfma(w1[k], t, ak[1] + w2[k]);
+            ak[2] = gfma(w1[k], t2, gfma(w2[k], d2, ak[2]));
+            ak[3] = gfma(w1[k], t3, gfma(w2[k], d3, ak[3]));
+            ak[4] = gfma(w1[k], t4, gfma(w2[k], d4, ak[4]));
+            ak[5] = gfma(w1[k], t5, gfma(w2[k], d5, ak[5]));
             if (DYN) {
               ak[2] += w3[k] * (R)2;
               ak[3] += w3[k] * (R)6 * t;
@@ -634,8 +702,14 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
               ak[5] += w3[k] * (R)20 * t3;
             }
           }
-          if constexpr (SPL == 1) acc[18] = csum;
-          else acc[18] += csum;
+          acc[18] += csum;
+          }
+#ifdef GTOP_STAMPS
+          if (j0 == 0 && s0 == 0) {
+            asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[11]), "v"(acc[17]), "v"(acc[18]));
+            GTOP_STAMP(10);
+          }
+#endif
         }
         // A_s^-T on this lane's 18 accumulators (coefficient space -> [p0,pT,v0,vT,a0,aT]
         // per axis), so that the reduction below already yields what the free
@@ -681,6 +755,9 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
             // barrier, only a compiler-level ordering point.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#ifdef GTOP_STAMPS
+            if (s0 == 0 && c0 == 0) GTOP_STAMP(11);
+#endif
             // each lane owns up to kRdr (segment slot, value) sums; all tile reads are
             // issued before any result is stored (one LDS round trip, not kRdr)
             constexpr int kRdr = (SPW * kRedChunk + 63) / 64;
@@ -695,6 +772,9 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
               const R jerk = (ok & (c0 + v < 18)) ? Gs[Sr * 18 + c0 + v] : (R)0;
               sums[u] = jerk + tree_sum<R, LPS>(col);
             }
+#ifdef GTOP_STAMPS
+            if (s0 == 0 && c0 == 0) { asm volatile("" ::"v"(sums[0])); GTOP_STAMP(12); }
+#endif
 #pragma unroll
             for (int u = 0; u < kRdr; ++u) {
               const int r = lane + 64 * u;
@@ -734,6 +814,9 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
         gb[q] = v + (R)1e-5;
         if (MMA) gl[q] = v + (R)1e-5;
       }
+#ifdef GTOP_STAMPS
+      GTOP_STAMP(13);
+#endif
       for (int tl = wave; tl < ntraj; tl += NW) {   // one wavefront reduction per trajectory
         R part = (R)0;
         for (int i = lane; i < 3 * m; i += 64) part += ws * csm[tl * 3 * m + i];
@@ -825,8 +908,8 @@ hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMm
 }
 
 #ifdef GTOP_STAMPS
-extern "C" int gtop_debug_read_stamps(unsigned long long *out /*4096*8*/) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gtop_stamps), sizeof(unsigned long long) * 4096 * 8);
+extern "C" int gtop_debug_read_stamps(unsigned long long *out /*4096*16*/) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gtop_stamps), sizeof(unsigned long long) * 4096 * 16);
 }
 #endif
 

@@ -31,7 +31,7 @@ for _ in range(20):
     ctx.eval_device(x, Df, T, cost, grad)
 torch.cuda.synchronize()
 L = gtop.load_library()
-buf = np.zeros((4096, 8), dtype=np.uint64)
+buf = np.zeros((4096, 16), dtype=np.uint64)
 rc = L.gtop_debug_read_stamps(buf.ctypes.data_as(C.c_void_p))
 assert rc == 0
 nb = min(4096, B)
@@ -43,3 +43,10 @@ for i, nme in enumerate(names):
     print(f"  {nme:22s} median {np.median(d[:, i]):8.0f}   p10 {np.percentile(d[:, i], 10):8.0f}   p90 {np.percentile(d[:, i], 90):8.0f}")
 print(f"  total                  median {np.median(s[:, 6] - s[:, 0]):8.0f}")
 print(f"  first start -> last end: {(s[:, 6].max() - s[:, 0].min())} cycles; block start spread {(s[:, 0].max() - s[:, 0].min())}")
+
+f = buf[:nb].astype(np.int64)
+print("  fine (first sample chunk): start->issued %.0f, issued->loads landed %.0f, landed->consumed %.0f" % (
+    np.median(f[:, 8] - f[:, 2]), np.median(f[:, 9] - f[:, 8]), np.median(f[:, 10] - f[:, 9])))
+print("  fine: samples end->tile written %.0f, tile->sums %.0f, sums->barrier %.0f; phase4: gradient scatter %.0f, cost %.0f" % (
+    np.median(f[:, 11] - f[:, 3]), np.median(f[:, 12] - f[:, 11]), np.median(f[:, 4] - f[:, 12]),
+    np.median(f[:, 13] - f[:, 5]), np.median(f[:, 6] - f[:, 13])))
