@@ -88,17 +88,16 @@ template <> __device__ __forceinline__ double gexp<double>(double v) { return ex
 template <> __device__ __forceinline__ float gexp<float>(float v) { return expf(v); }
 
 // exp for the per-sample penalty (src/grad_traj_optimizer.cpp:509,:514): one
-// range reduction x = k ln2 + r, |r| <= ln2/2, a degree-13 Taylor/Horner
-// polynomial (truncation 4e-18 relative) and ldexp: < 2 ulp, about half the
-// instructions of the library routine.  Huge |x| saturate to 0 / inf through
-// v_ldexp_f64; NaN propagates.
+// range reduction x = k ln2 + r, |r| <= ln2/2, a degree-11 Taylor/Horner
+// polynomial (truncation 6e-15 relative) and ldexp — about a third of the
+// instructions of the library routine.  |x| beyond the fp64 exponent range
+// saturates to 0 / inf through v_cvt_i32_f64 (saturating) and v_ldexp_f64;
+// NaN propagates through p.
 __device__ __forceinline__ double penalty_exp(double x) {
   const double k = rint(x * 1.4426950408889634074);            // x / ln2
   double r = fma(k, -6.93147180369123816490e-01, x);            // ln2 hi
   r = fma(k, -1.90821492927058770002e-10, r);                   // ln2 lo
-  double p = 1.6059043836821613e-10;                            // 1/13!
-  p = fma(p, r, 2.08767569878681e-09);                          // 1/12!
-  p = fma(p, r, 2.505210838544172e-08);                         // 1/11!
+  double p = 2.505210838544172e-08;                             // 1/11!
   p = fma(p, r, 2.755731922398589e-07);                         // 1/10!
   p = fma(p, r, 2.7557319223985893e-06);                        // 1/9!
   p = fma(p, r, 2.48015873015873e-05);                          // 1/8!
@@ -110,8 +109,7 @@ __device__ __forceinline__ double penalty_exp(double x) {
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  const double kc = fmin(fmax(k, -2100.0), 2100.0);             // keep the int conversion defined
-  return ldexp(p, (int)kc);
+  return ldexp(p, (int)k);   // v_cvt_i32_f64: saturating, NaN -> 0
 }
 __device__ __forceinline__ float penalty_exp(float x) { return expf(x); }
 
@@ -123,6 +121,12 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return y;
 }
 __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+// 1/x to ~1e-15: hardware estimate + one Newton step (used where the result only scales a gradient term)
+__device__ __forceinline__ double quick_rcp(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, y, 1.0), y, y);
+}
+__device__ __forceinline__ float quick_rcp(float x) { return 1.0f / x; }
 template <typename R> __device__ __forceinline__ R gfma(R a, R b, R c);
 template <> __device__ __forceinline__ double gfma<double>(double a, double b, double c) { return fma(a, b, c); }
 template <> __device__ __forceinline__ float gfma<float>(float a, float b, float c) { return fmaf(a, b, c); }
@@ -143,6 +147,12 @@ __device__ __forceinline__ double speed_sqrt(double s) {
   return g;
 }
 __device__ __forceinline__ float speed_sqrt(float s) { return sqrtf(s); }
+template <typename R> __device__ __forceinline__ R gmin(R a, R b);
+template <> __device__ __forceinline__ double gmin<double>(double a, double b) { return fmin(a, b); }
+template <> __device__ __forceinline__ float gmin<float>(float a, float b) { return fminf(a, b); }
+template <typename R> __device__ __forceinline__ R gmax(R a, R b);
+template <> __device__ __forceinline__ double gmax<double>(double a, double b) { return fmax(a, b); }
+template <> __device__ __forceinline__ float gmax<float>(float a, float b) { return fmaxf(a, b); }
 template <typename R> __device__ __forceinline__ R gfloor(R v);
 template <> __device__ __forceinline__ double gfloor<double>(double v) { return floor(v); }
 template <> __device__ __forceinline__ float gfloor<float>(float v) { return floorf(v); }
@@ -160,6 +170,45 @@ __device__ __forceinline__ float round_through_float(float v) { return v; }
 // grad uninitialised there, this build defines it as 0.
 // Branch-free: the corner indices are clamped anyway (:166-174), so the loads
 // are always in bounds and the out-of-map case is a final select.
+// The four (x,y) corner columns of a lookup, each loaded as the pair
+// (D[..][zb], D[..][zb+1]).  Per-axis clamp of the corner indices as in
+// src/sdf_map.cpp:166-174: x0 = clamp(ix), x1 = clamp(ix+1), so x1 = x0 + 1
+// exactly when 0 <= ix <= nx-2 and x1 = x0 otherwise (same for y) — the second
+// column is the first plus a stride that is selected to zero at the borders.
+// WIDE = false (the host checks nx*ny < 2^24, nz < 2^24, field < 4 GiB):
+// 24-bit multiplies (full rate; v_mul_lo_u32 is not) and a uniform base +
+// 32-bit byte offset per lane.  WIDE = true: 64-bit indices, any field.
+template <typename R, bool WIDE>
+__device__ __forceinline__ int corner_loads(const GtopKernelArgs<R> &a, int ix, int iy, int iz,
+                                            Pair<R> &p00, Pair<R> &p01, Pair<R> &p10, Pair<R> &p11) {
+  const int nx = a.nx, ny = a.ny, nz = a.nz;
+  const int x0 = min(max(ix, 0), nx - 1);
+  const int y0 = min(max(iy, 0), ny - 1);
+  const int zb = min(max(iz, 0), nz - 2);
+  const bool cx = (unsigned)ix < (unsigned)(nx - 1), cy = (unsigned)iy < (unsigned)(ny - 1);
+  if constexpr (!WIDE) {
+    const char *D = reinterpret_cast<const char *>(a.sdf);
+    constexpr uint32_t esz = (uint32_t)sizeof(R);
+    const uint32_t o00 = (__umul24(__umul24((uint32_t)x0, (uint32_t)ny) + (uint32_t)y0, (uint32_t)nz) + (uint32_t)zb) * esz;
+    const uint32_t sy = cy ? (uint32_t)nz * esz : 0u;
+    const uint32_t sx = cx ? (uint32_t)ny * (uint32_t)nz * esz : 0u;
+    const uint32_t o10 = o00 + sx;
+    p00 = *reinterpret_cast<const Pair<R> *>(D + o00);
+    p01 = *reinterpret_cast<const Pair<R> *>(D + (o00 + sy));
+    p10 = *reinterpret_cast<const Pair<R> *>(D + o10);
+    p11 = *reinterpret_cast<const Pair<R> *>(D + (o10 + sy));
+  } else {
+    const R *D = a.sdf;
+    const size_t i00 = ((size_t)x0 * ny + y0) * nz + zb;
+    const size_t sy = cy ? (size_t)nz : 0, sx = cx ? (size_t)ny * nz : 0;
+    p00 = *reinterpret_cast<const Pair<R> *>(D + i00);
+    p01 = *reinterpret_cast<const Pair<R> *>(D + i00 + sy);
+    p10 = *reinterpret_cast<const Pair<R> *>(D + i00 + sx);
+    p11 = *reinterpret_cast<const Pair<R> *>(D + i00 + sx + sy);
+  }
+  return zb;
+}
+
 // The query is split in two so that a caller can put several lookups in flight
 // before consuming the first: sdf_issue does the index arithmetic and issues the
 // four pair loads, sdf_blend is the trilinear arithmetic on the loaded corners.
@@ -169,7 +218,7 @@ template <typename R> struct SdfTap {
   bool out, zflat;              // outside the map; clamped at a z border (zero z-gradient)
 };
 
-template <typename R>
+template <typename R, bool WIDE>
 __device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, R px, R py, R pz) {
   SdfTap<R> tp;
   tp.out = (px < a.lo[0]) | (py < a.lo[1]) | (pz < a.lo[2]) |
@@ -180,33 +229,21 @@ __device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, R px,
   const R ux = ((px - half) - a.origin[0]) * rinv;
   const R uy = ((py - half) - a.origin[1]) * rinv;
   const R uz = ((pz - half) - a.origin[2]) * rinv;
-  const R fx = gfloor(ux), fy = gfloor(uy), fz = gfloor(uz);
-  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+  const R fx = gfloor(ux), fy = gfloor(uy);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)gfloor(uz);
   // indexToPos (:76-78) and diff (:209): (pos - centre(idx)) / res is the fractional
   // part of u (equal up to a few ulp of u, ~1e-14 of a voxel)
   tp.dx = ux - fx;
   tp.dy = uy - fy;
-  const R dz = uz - fz;
 
-  // per-axis clamp of the 8 corner indices (:166-174).  z is the fastest
-  // axis, so the two z-corners of each (x,y) column are one 2-element load;
-  // the clamp at the z borders becomes a select on that pair.
-  const int nx = a.nx, ny = a.ny, nz = a.nz;
-  const int x0 = min(max(ix, 0), nx - 1), x1 = min(max(ix + 1, 0), nx - 1);
-  const int y0 = min(max(iy, 0), ny - 1), y1 = min(max(iy + 1, 0), ny - 1);
-  const int zb = min(max(iz, 0), nz - 2);
-  const bool z_lo = iz < 0, z_hi = iz > nz - 2;
-  const R *D = a.sdf;
-  const uint32_t row0 = (uint32_t)x0 * ny, row1 = (uint32_t)x1 * ny;
-  tp.p00 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y0) * nz + zb));
-  tp.p01 = *reinterpret_cast<const Pair<R> *>(D + ((row0 + y1) * nz + zb));
-  tp.p10 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y0) * nz + zb));
-  tp.p11 = *reinterpret_cast<const Pair<R> *>(D + ((row1 + y1) * nz + zb));
+  // z is the fastest axis, so the two z-corners of each (x,y) column are one
+  // 2-element load; the clamp at the z borders becomes a clamp of the weight.
+  const int zb = corner_loads<R, WIDE>(a, ix, iy, iz, tp.p00, tp.p01, tp.p10, tp.p11);
   // At a z border both z-corners clamp to the same voxel (:166-174); with the
-  // pair (D[zb], D[zb+1]) in hand that is dz := 0 (iz = -1) or dz := 1
-  // (iz = nz-1) and a zero z-gradient.
-  tp.dze = z_lo ? (R)0 : (z_hi ? (R)1 : dz);
-  tp.zflat = z_lo | z_hi;
+  // pair (D[zb], D[zb+1]) in hand that is dz := 0 (iz < 0) or dz := 1
+  // (iz > nz-2) — i.e. uz - zb clamped to [0,1] — and a zero z-gradient.
+  tp.dze = gmin(gmax(uz - (R)zb, (R)0), (R)1);
+  tp.zflat = iz != zb;
   return tp;
 }
 
@@ -266,6 +303,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
 
 // two SDFMap::getDistWithGradTrilinear queries (src/sdf_map.cpp:185-242)
+template <bool WIDE>
 __device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 px, f2 py, f2 pz,
                                              f2 &gx, f2 &gy, f2 &gz, bool &outA, bool &outB) {
   outA = (px.x < a.lo[0]) | (py.x < a.lo[1]) | (pz.x < a.lo[2]) | (px.x > a.hi[0]) | (py.x > a.hi[1]) | (pz.x > a.hi[2]);
@@ -281,21 +319,13 @@ __device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 
   const f2 dy = (py - ((fy + h) * res + oy)) * rinv;
   f2 dz = (pz - ((fz + h) * res + oz)) * rinv;
 
-  const int nx = a.nx, ny = a.ny, nz = a.nz;
-  const float *D = a.sdf;
+  const int nz = a.nz;
   Pair<float> p00[2], p01[2], p10[2], p11[2];
   bool zflat[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int ix = (int)(c ? fx.y : fx.x), iy = (int)(c ? fy.y : fy.x), iz = (int)(c ? fz.y : fz.x);
-    const int x0 = min(max(ix, 0), nx - 1), x1 = min(max(ix + 1, 0), nx - 1);
-    const int y0 = min(max(iy, 0), ny - 1), y1 = min(max(iy + 1, 0), ny - 1);
-    const int zb = min(max(iz, 0), nz - 2);
-    const uint32_t row0 = (uint32_t)x0 * ny, row1 = (uint32_t)x1 * ny;
-    p00[c] = *reinterpret_cast<const Pair<float> *>(D + ((row0 + y0) * nz + zb));
-    p01[c] = *reinterpret_cast<const Pair<float> *>(D + ((row0 + y1) * nz + zb));
-    p10[c] = *reinterpret_cast<const Pair<float> *>(D + ((row1 + y0) * nz + zb));
-    p11[c] = *reinterpret_cast<const Pair<float> *>(D + ((row1 + y1) * nz + zb));
+    corner_loads<float, WIDE>(a, ix, iy, iz, p00[c], p01[c], p10[c], p11[c]);
     // z border (:166-174): both z-corners clamp to the same voxel.  With the
     // pair (D[zb], D[zb+1]) loaded, that is dz := 0 (iz = -1) or 1 (iz = nz-1)
     // and a zero z-gradient.
@@ -332,7 +362,7 @@ __device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 
 // Two samples (t.x, t.y) of one segment: everything phase 2 does per sample
 // (src/grad_traj_optimizer.cpp:353-381), accumulated component-wise into
 // acc2[19]; the caller adds the two components after its loop.
-template <bool DYN>
+template <bool DYN, bool WIDE>
 __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, const float *cq, f2 t,
                                                 bool liveA, bool liveB, float wdt, float dt, f2 (&acc2)[kRedVals]) {
   const f2 t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
@@ -349,7 +379,7 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
   const f2 ivn = {__builtin_amdgcn_rcpf(vn.x), __builtin_amdgcn_rcpf(vn.y)};
   f2 g3[3];
   bool outA, outB;
-  f2 dist = sdf_query_pair(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2], outA, outB);   // :363
+  f2 dist = sdf_query_pair<WIDE>(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2], outA, outB);   // :363
   if (outA) dist.x = -1.0f;   // out of map (sdf_map.cpp:187): dist = -1, grad := 0
   if (outB) dist.y = -1.0f;
   const f2 arg = (splat(a.d0) - dist) * splat(a.inv_r);
@@ -433,7 +463,7 @@ template <> struct MinWaves<float> { static constexpr int v = GTOP_F32_MIN_WAVES
 // point st.xcur of the lock-step CCSA-MMA driver, and after cost and gradient of
 // a trajectory are known the same workgroup runs its MMA update
 // (gtop_mma_update_trajectory) — one launch per optimizer iteration.
-template <typename R, bool DYN, int SPL, bool MMA>
+template <typename R, bool DYN, int SPL, bool MMA, bool WIDE>
 __global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R>::v)) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
@@ -578,7 +608,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
               t = (f2){ta, tb};
             }
             const bool liveA = seg_ok & (t.x < (float)Tseg), liveB = seg_ok & (t.y < (float)Tseg);
-            sample_pair_f32<DYN>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, t, liveA, liveB,
+            sample_pair_f32<DYN, WIDE>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, t, liveA, liveB,
                                  (float)wdt, (float)dt, acc2);
           }
 #pragma unroll
@@ -622,7 +652,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
               if (DYN)  // :497-502
                 accs[c][k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
             }
-            taps[c] = sdf_issue(a, pos[0], pos[1], pos[2]);   // :363
+            taps[c] = sdf_issue<R, WIDE>(a, pos[0], pos[1], pos[2]);   // :363
           }
           if constexpr (CH > 1) __builtin_amdgcn_sched_barrier(0);   // keep every load of stage A above stage B
 #ifdef GTOP_STAMPS
@@ -640,7 +670,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
           const R *vel = vels[c], *acc3 = accs[c];
           const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
           const R vn = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;  // :358
-          const R ivn = fast_rcp(vn);
+          const R ivn = quick_rcp(vn);
           R g3[3];
           bool is_out;
           const R dist = sdf_blend(a, taps[c], g3[0], g3[1], g3[2], is_out);
@@ -849,27 +879,33 @@ size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem) {
 
 int gtop_eval_segments_per_wave(int spl) { return 64 / (kSamples / spl); }
 
-template <typename R, bool DYN, bool MMA>
+// WIDE = false needs 24-bit row/column counts and a field below 4 GiB (corner_loads)
+bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
+  const unsigned long long nvox = (unsigned long long)nx * ny * nz;
+  return (unsigned long long)nx * ny < (1ull << 24) && nz < (1 << 24) && (nvox + 2) * elem < (1ull << 32);
+}
+
+template <typename R, bool DYN, bool MMA, bool WIDE>
 static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, int grid,
                              size_t smem, hipStream_t stream) {
   void (*kern)(const GtopKernelArgs<R>, const GtopMmaState) = nullptr;
   if constexpr (MMA) {   // the fused optimizer step is built for the two geometries the auto rule picks
     switch (spl) {
-      case 1: kern = gtop_eval_kernel<R, DYN, 1, true>; break;
-      case 3: kern = gtop_eval_kernel<R, DYN, 3, true>; break;
-      case 6: kern = gtop_eval_kernel<R, DYN, 6, true>; break;
+      case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE>; break;
+      case 3: kern = gtop_eval_kernel<R, DYN, 3, true, WIDE>; break;
+      case 6: kern = gtop_eval_kernel<R, DYN, 6, true, WIDE>; break;
       default: return hipErrorInvalidValue;
     }
   } else {
     switch (spl) {
-      case 1: kern = gtop_eval_kernel<R, DYN, 1, false>; break;
-      case 2: kern = gtop_eval_kernel<R, DYN, 2, false>; break;
-      case 3: kern = gtop_eval_kernel<R, DYN, 3, false>; break;
-      case 5: kern = gtop_eval_kernel<R, DYN, 5, false>; break;
-      case 6: kern = gtop_eval_kernel<R, DYN, 6, false>; break;
-      case 10: kern = gtop_eval_kernel<R, DYN, 10, false>; break;
-      case 15: kern = gtop_eval_kernel<R, DYN, 15, false>; break;
-      case 30: kern = gtop_eval_kernel<R, DYN, 30, false>; break;
+      case 1: kern = gtop_eval_kernel<R, DYN, 1, false, WIDE>; break;
+      case 2: kern = gtop_eval_kernel<R, DYN, 2, false, WIDE>; break;
+      case 3: kern = gtop_eval_kernel<R, DYN, 3, false, WIDE>; break;
+      case 5: kern = gtop_eval_kernel<R, DYN, 5, false, WIDE>; break;
+      case 6: kern = gtop_eval_kernel<R, DYN, 6, false, WIDE>; break;
+      case 10: kern = gtop_eval_kernel<R, DYN, 10, false, WIDE>; break;
+      case 15: kern = gtop_eval_kernel<R, DYN, 15, false, WIDE>; break;
+      case 30: kern = gtop_eval_kernel<R, DYN, 30, false, WIDE>; break;
       default: return hipErrorInvalidValue;
     }
   }
@@ -882,29 +918,33 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
   return hipGetLastError();
 }
 
-template <typename R>
-hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
-                            int max_blocks, hipStream_t stream) {
+template <typename R, bool MMA>
+static hipError_t launch_any(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, bool dyn,
+                             int max_blocks, hipStream_t stream) {
   if (args.B <= 0) return hipSuccess;
   const size_t smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, sizeof(R));
   const int groups = (args.B + args.tpb - 1) / args.tpb;
   const int vblocks = 8 * ((groups + 7) / 8);   // the kernel walks 8 XCD-contiguous ranges
   const int grid = vblocks < max_blocks ? vblocks : max_blocks;
+  const bool wide = !gtop_field_is_narrow(args.nx, args.ny, args.nz, sizeof(R));
+  if (wide)
+    return dyn ? launch_spl<R, true, MMA, true>(args, st, waves, spl, grid, smem, stream)
+               : launch_spl<R, false, MMA, true>(args, st, waves, spl, grid, smem, stream);
+  return dyn ? launch_spl<R, true, MMA, false>(args, st, waves, spl, grid, smem, stream)
+             : launch_spl<R, false, MMA, false>(args, st, waves, spl, grid, smem, stream);
+}
+
+template <typename R>
+hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
+                            int max_blocks, hipStream_t stream) {
   const GtopMmaState none{};
-  return dyn ? launch_spl<R, true, false>(args, none, waves, spl, grid, smem, stream)
-             : launch_spl<R, false, false>(args, none, waves, spl, grid, smem, stream);
+  return launch_any<R, false>(args, none, waves, spl, dyn, max_blocks, stream);
 }
 
 // cost/gradient at st.xcur + the MMA update, one launch (fp64; spl 1, 3 or 6)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
                                 bool dyn, int max_blocks, hipStream_t stream) {
-  if (args.B <= 0) return hipSuccess;
-  const size_t smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, sizeof(double));
-  const int groups = (args.B + args.tpb - 1) / args.tpb;
-  const int vblocks = 8 * ((groups + 7) / 8);
-  const int grid = vblocks < max_blocks ? vblocks : max_blocks;
-  return dyn ? launch_spl<double, true, true>(args, st, waves, spl, grid, smem, stream)
-             : launch_spl<double, false, true>(args, st, waves, spl, grid, smem, stream);
+  return launch_any<double, true>(args, st, waves, spl, dyn, max_blocks, stream);
 }
 
 #ifdef GTOP_STAMPS

@@ -65,3 +65,41 @@ def test_fp64_parity_every_launch_geometry(scene, oracle_mod, m, spl, waves):
     c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params(**kw))
     rc, rg = rel_err(c, g, c_ref, g_ref)
     assert rc <= TOL64 and rg <= TOL64, (rc, rg)
+
+
+def test_parity_wide_index_field(gtop, oracle_mod):
+    """A flat map with nx*ny >= 2^24 takes the 64-bit-index variant of the lookup
+    (corner_loads<WIDE>); same arithmetic, so the same bound.  The field is
+    synthetic (smooth + noise), handed over with gtop_set_sdf."""
+    import types
+    grid = (4097, 4097, 6)
+    res = 0.2
+    origin = np.array([-grid[0] * res / 2, -grid[1] * res / 2, 0.0])
+    map_size = np.array(grid) * res
+    rng = np.random.default_rng(5)
+    dist = rng.uniform(0.0, 2.0, size=grid[0] * grid[1] * grid[2])
+    ms = types.SimpleNamespace(origin=origin, map_size=map_size)
+    b = problem.make_trajectories(96, 6, ms, seed=77, margin=0.15, step_len=(0.5, 1.5))
+    ctx = gtop.GtopContext(device=0)
+    ctx.set_sdf(dist, grid, origin, res)
+    sdf = oracle_mod.Sdf(origin, res, grid, dist)
+    ctx.set_params()
+    ctx.set_problem(b.T, b.Df)
+    for spl in (3, 6):
+        ctx.set_launch_geometry(0, spl)
+        c, g = ctx.eval_batch(b.x)
+        c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params())
+        rc, rg = rel_err(c, g, c_ref, g_ref)
+        assert rc <= TOL64 and rg <= TOL64, (spl, rc, rg)
+    # fp32 entry on the same field: the packed path's wide variant (bound as in test_gpu_api)
+    import torch
+    dev = torch.device("cuda:0")
+    x = torch.tensor(b.x, dtype=torch.float32, device=dev)
+    Df = torch.tensor(b.Df.reshape(-1, 18), dtype=torch.float32, device=dev)
+    T = torch.tensor(b.T, dtype=torch.float32, device=dev)
+    for spl in (3, 6):
+        ctx.set_launch_geometry(0, spl)
+        c32, g32 = ctx.eval_device(x, Df, T)
+        torch.cuda.synchronize()
+        rc, rg = rel_err(c32.cpu().numpy().astype(np.float64), g32.cpu().numpy().astype(np.float64), c_ref, g_ref)
+        assert rc <= 2e-3 and rg <= 2e-3, (spl, rc, rg)
