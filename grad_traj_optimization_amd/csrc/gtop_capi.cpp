@@ -194,9 +194,9 @@ int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const 
   a.B = B; a.m = m; a.t_stride = t_stride;
   int waves, spl, tpb;
   launch_geometry(c, B, m, &waves, &spl, &tpb);
-  while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, sizeof(R)) > 64 * 1024) --tpb;
+  while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(R)) > 64 * 1024) --tpb;
   a.tpb = tpb;
-  if (gtop_eval_smem_bytes(m, waves, tpb, sizeof(R)) > 160 * 1024)
+  if (gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(R)) > 160 * 1024)
     return fail(c, GTOP_ERR_INVALID, "m too large for one workgroup's LDS");
   HIPCHK(c, gtop_launch_eval<R>(a, waves, spl, c->prm.enable_dyn != 0, 1 << 20, stream));
   return GTOP_OK;
@@ -596,7 +596,7 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
       a.cost = c->mma_f;
       a.grad = c->mma_g;
       a.B = B; a.m = m; a.t_stride = time_stride;
-      while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, sizeof(double)) > 64 * 1024) --tpb;
+      while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(double)) > 64 * 1024) --tpb;
       a.tpb = tpb;
       HIPCHK(c, gtop_launch_eval_mma(a, st, waves, spl, c->prm.enable_dyn != 0, 1 << 20, s));
     } else {

@@ -39,7 +39,7 @@ struct GtopMmaState {
   double *rho, *minf, *gval, *wval;                       // [B]
   int *k, *state;                                         // [B]
 };
-size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem);
+size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem);
 
 // spl = samples per lane (a divisor of 30); a wavefront then holds
 // gtop_eval_segments_per_wave(spl) segments.

@@ -43,6 +43,9 @@ namespace {
 #ifndef GTOP_F64_MIN_WAVES
 #define GTOP_F64_MIN_WAVES 2
 #endif
+#ifndef GTOP_F64_MIN_WAVES_ROLLED
+#define GTOP_F64_MIN_WAVES_ROLLED 3
+#endif
 #ifndef GTOP_F32_MIN_WAVES
 #define GTOP_F32_MIN_WAVES 3
 #endif
@@ -53,7 +56,11 @@ namespace {
 #endif
 constexpr int kSamples = 30;     // src/grad_traj_optimizer.cpp:351
 constexpr int kRedVals = 19;     // 18 gradient entries + 1 cost per sample
-constexpr int kRedStride = 65;   // 64 lanes + 1 pad: conflict-free column reads
+// row stride of the transpose-reduction tile: the busy lanes of a wave (LPS*SPW of 64), made odd
+constexpr int red_stride(int spl) {
+  const int lps = kSamples / spl, busy = lps * (64 / lps);
+  return busy | 1;
+}
 #ifndef GTOP_PREISSUE
 #define GTOP_PREISSUE 0
 #endif
@@ -453,10 +460,15 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
 //                              (small, latency-bound batches)
 //   SPL = 3, NW = 1, TPB = 1 : one wavefront per trajectory (60/64 lanes)
 //   SPL = 15, NW = 1, TPB = 5: 2 lanes per segment, 5 trajectories per wavefront
-// Register budget: the fp32 bodies fit 128 VGPRs (4 waves per SIMD) with at most
-// a couple of spilled dwords; the fp64 bodies need their ~190.
-template <typename R> struct MinWaves { static constexpr int v = GTOP_F64_MIN_WAVES; };
-template <> struct MinWaves<float> { static constexpr int v = GTOP_F32_MIN_WAVES; };
+// Register budget (waves per SIMD the compiler must leave room for).  fp64: the
+// rolled sample loops (SPL >= 5, the large-batch geometries) fit 168 VGPRs = 3
+// waves per SIMD without spilling; the unrolled small-batch bodies need ~210 and
+// the optional velocity/acceleration block (DYN) more.  fp32: 3 waves; the
+// 128-VGPR budget of 4 waves spills.
+template <typename R, int SPL, bool DYN> struct MinWaves {
+  static constexpr int v = (!DYN && (SPL == 5 || SPL == 6)) ? GTOP_F64_MIN_WAVES_ROLLED : GTOP_F64_MIN_WAVES;
+};
+template <int SPL, bool DYN> struct MinWaves<float, SPL, DYN> { static constexpr int v = DYN ? 2 : GTOP_F32_MIN_WAVES; };
 
 //
 // MMA = true (fp64 only) appends the optimizer step: `a.x` is then the trial
@@ -464,13 +476,14 @@ template <> struct MinWaves<float> { static constexpr int v = GTOP_F32_MIN_WAVES
 // a trajectory are known the same workgroup runs its MMA update
 // (gtop_mma_update_trajectory) — one launch per optimizer iteration.
 template <typename R, bool DYN, int SPL, bool MMA, bool WIDE>
-__global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R>::v)) GTOP_WAVES_PER_EU_ATTR
+__global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R, SPL, DYN>::v)) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront
+  constexpr int kRedStride = red_stride(SPL);
   // up to three samples per lane are unrolled outright (the small-batch geometry: one wavefront per SIMD,
   // the scheduler interleaves the samples); longer loops stay rolled to hold 2 waves per SIMD
-  constexpr int kUnroll = (SPL <= 3) ? SPL : GTOP_SAMPLE_UNROLL;
+  constexpr int kUnroll = (SPL <= 3 && !DYN) ? SPL : GTOP_SAMPLE_UNROLL;
   constexpr int CH = (GTOP_PREISSUE && SPL <= 3) ? SPL : 1;   // distance-field lookups in flight per lane
   static_assert(LPS * SPL == kSamples, "SPL must divide 30");
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -485,12 +498,12 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   R *coef = Ts + MS;         // [MS][3][6] polynomial coefficients (:253-279)
   R *Gs = coef + 18 * MS;    // [MS][3][6] jerk gradient, derivative space
   R *csm = Gs + 18 * MS;     // [MS][3]    jerk cost per (segment, axis)
-  R *ccol = csm + 3 * MS;    // [MS]       wc * collision (+dyn) cost per segment
-  R *dts = ccol + MS;        // [MS]       T_s / 30 (:351)
-  R *iTs = dts + MS;         // [MS]       1 / T_s
+  R *dts = csm + 3 * MS;     // [MS]       T_s / 30 (:351)
+  R *ccol = Ts;              // [MS]       wc * collision (+dyn) cost per segment; takes the place of T_s,
+                             //            which only the segment's own wavefront reads, before it writes this
   R *gseg = coef;            // [MS][3][6] total gradient per segment, derivative space [p0,pT,v0,vT,a0,aT];
                              //            written by a wavefront over ITS segments' coef after its sample loop
-  R *red = iTs + MS;         // [NW][kRedChunk][65] per-wave transpose-reduction tile
+  R *red = dts + MS;         // [NW][kRedChunk][kRedStride] per-wave transpose-reduction tile
   R *myred = red + wave * (kRedChunk * kRedStride);
 
   const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
@@ -555,9 +568,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
       g[5] = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
       if (k == 0) {
         Ts[S] = T;
-        iTs[S] = iT;
         dts[S] = T / (R)30.0;   // :351
-        ccol[S] = (R)0;
+        if (!do_colli) ccol[S] = (R)0;   // (aliases Ts: only when the sample phase will not read it)
       }
     }
     __syncthreads();
@@ -745,7 +757,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
         // per axis), so that the reduction below already yields what the free
         // variables gather; the map is linear, so it commutes with the sums.
         {
-          const R T = Tseg, T2 = T * T, iT = iTs[sc];
+          const R T = Tseg, T2 = T * T, iT = fast_rcp(T);
           const R iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -779,7 +791,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
             const int cn = (kRedVals - c0) < kRedChunk ? (kRedVals - c0) : kRedChunk;
 #pragma unroll
             for (int v = 0; v < kRedChunk; ++v)
-              if (v < cn) myred[v * kRedStride + lane] = acc[c0 + v];
+              if ((v < cn) & (lane < LPS * SPW)) myred[v * kRedStride + lane] = acc[c0 + v];
             // The tile belongs to this wavefront alone (writers and readers are its own
             // lanes), and a wavefront's LDS operations execute in order: no workgroup
             // barrier, only a compiler-level ordering point.
@@ -870,10 +882,9 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
 
 }  // namespace
 
-size_t gtop_eval_smem_bytes(int m, int waves, int tpb, size_t elem) {
+size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem) {
   const size_t MS = (size_t)tpb * m;
-  size_t elems = MS + 18 * MS * 2 + 3 * MS + MS + MS + MS +
-                 (size_t)waves * kRedChunk * kRedStride;
+  const size_t elems = MS + 18 * MS * 2 + 3 * MS + MS + (size_t)waves * kRedChunk * red_stride(spl);
   return elems * elem;
 }
 
@@ -922,7 +933,7 @@ template <typename R, bool MMA>
 static hipError_t launch_any(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, bool dyn,
                              int max_blocks, hipStream_t stream) {
   if (args.B <= 0) return hipSuccess;
-  const size_t smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, sizeof(R));
+  const size_t smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R));
   const int groups = (args.B + args.tpb - 1) / args.tpb;
   const int vblocks = 8 * ((groups + 7) / 8);   // the kernel walks 8 XCD-contiguous ranges
   const int grid = vblocks < max_blocks ? vblocks : max_blocks;
