@@ -308,6 +308,7 @@ __device__ __forceinline__ R tree_sum(const R *p) {
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // two SDFMap::getDistWithGradTrilinear queries (src/sdf_map.cpp:185-242)
 template <bool WIDE>
@@ -373,12 +374,13 @@ template <bool DYN, bool WIDE>
 __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, const float *cq, f2 t,
                                                 bool liveA, bool liveB, float wdt, float dt, f2 (&acc2)[kRedVals]) {
   const f2 t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+  const f2 d2 = splat(2.0f) * t, d3 = splat(3.0f) * t2, d4 = splat(4.0f) * t3, d5 = splat(5.0f) * t4;   // d/dt of the powers
   f2 pos[3], vel[3], acc3[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float *q = cq + 6 * k;
     pos[k] = splat(q[0]) + splat(q[1]) * t + splat(q[2]) * t2 + splat(q[3]) * t3 + splat(q[4]) * t4 + splat(q[5]) * t5;
-    vel[k] = splat(q[1]) + splat(2.0f * q[2]) * t + splat(3.0f * q[3]) * t2 + splat(4.0f * q[4]) * t3 + splat(5.0f * q[5]) * t4;
+    vel[k] = splat(q[1]) + splat(q[2]) * d2 + splat(q[3]) * d3 + splat(q[4]) * d4 + splat(q[5]) * d5;
     if (DYN) acc3[k] = splat(2.0f * q[2]) + splat(6.0f * q[3]) * t + splat(12.0f * q[4]) * t2 + splat(20.0f * q[5]) * t3;
   }
   const f2 v2 = vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2];
@@ -429,16 +431,16 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
     if (!liveA) { csum.x = 0.0f; w2[0].x = w2[1].x = w2[2].x = 0.0f; w3[0].x = w3[1].x = w3[2].x = 0.0f; }
     if (!liveB) { csum.y = 0.0f; w2[0].y = w2[1].y = w2[2].y = 0.0f; w3[0].y = w3[1].y = w3[2].y = 0.0f; }
   }
-  const f2 d2 = splat(2.0f) * t, d3 = splat(3.0f) * t2, d4 = splat(4.0f) * t3, d5 = splat(5.0f) * t4;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     f2 *ak = acc2 + 6 * k;
+    // two fused multiply-adds per entry
     ak[0] += w1[k];
-    ak[1] += w1[k] * t + w2[k];
-    ak[2] += w1[k] * t2 + w2[k] * d2;
-    ak[3] += w1[k] * t3 + w2[k] * d3;
-    ak[4] += w1[k] * t4 + w2[k] * d4;
-    ak[5] += w1[k] * t5 + w2[k] * d5;
+    ak[1] = pk_fma(w1[k], t, ak[1] + w2[k]);
+    ak[2] = pk_fma(w1[k], t2, pk_fma(w2[k], d2, ak[2]));
+    ak[3] = pk_fma(w1[k], t3, pk_fma(w2[k], d3, ak[3]));
+    ak[4] = pk_fma(w1[k], t4, pk_fma(w2[k], d4, ak[4]));
+    ak[5] = pk_fma(w1[k], t5, pk_fma(w2[k], d5, ak[5]));
     if (DYN) {
       ak[2] += w3[k] * splat(2.0f);
       ak[3] += w3[k] * splat(6.0f) * t;
@@ -612,7 +614,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
             const float *cq = reinterpret_cast<const float *>(coef) + coff;
             const int si = li + jj * LPS;
             f2 t = {(float)si * (float)dt + 1e-3f, (float)(si + LPS) * (float)dt + 1e-3f};
-            if (tiny_T) {   // rare: exact replay of `t += dt`
+            if (any_tiny && tiny_T) {   // rare (the first test is wave-uniform): exact replay of `t += dt`
               float ta = 1e-3f;
               for (int i = 0; i < si; ++i) ta += (float)dt;
               float tb = ta;
