@@ -254,32 +254,28 @@ __device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, R px,
   return tp;
 }
 
+// Trilinear value and gradient (src/sdf_map.cpp:211-241) in difference form:
+// every interpolation is a + w (b - a), and the corner differences it needs are
+// the ones the gradient is made of, so nothing is computed twice.  The gradient
+// comes back UNSCALED — in distance per voxel; the caller folds 1/resolution
+// (:231-239) into the weight that multiplies it.
 template <typename R>
-__device__ __forceinline__ R sdf_blend(const GtopKernelArgs<R> &a, const SdfTap<R> &tp,
-                                       R &gx, R &gy, R &gz, bool &is_out) {
-  const R rinv = a.res_inv;
+__device__ __forceinline__ R sdf_blend(const SdfTap<R> &tp, R &gx, R &gy, R &gz, bool &is_out) {
   const R dx = tp.dx, dy = tp.dy, dze = tp.dze;
   // values[x][y][z]
   const R v000 = tp.p00.x, v001 = tp.p00.y, v010 = tp.p01.x, v011 = tp.p01.y;
-  const R v100 = tp.p10.x, v101 = tp.p10.y, v110 = tp.p11.x, v111 = tp.p11.y;
-
-  const R one = (R)1;
-  const R ex = one - dx, ey = one - dy, ez = one - dze;
-  const R v00 = ex * v000 + dx * v100;  // :221-224
-  const R v01 = ex * v001 + dx * v101;
-  const R v10 = ex * v010 + dx * v110;
-  const R v11 = ex * v011 + dx * v111;
-  const R v0 = ey * v00 + dy * v10;     // :226-227
-  const R v1 = ey * v01 + dy * v11;
-  const R dist = ez * v0 + dze * v1;    // :229
-  const R gzz = (v1 - v0) * rinv;       // :231
-  gy = (ez * (v10 - v00) + dze * (v11 - v01)) * rinv;  // :232-233
-  R g0 = ez * ey * (v100 - v000);       // :234-239
-  g0 += ez * dy * (v110 - v010);
-  g0 += dze * ey * (v101 - v001);
-  g0 += dze * dy * (v111 - v011);
-  gx = g0 * rinv;
-  gz = tp.zflat ? (R)0 : gzz;
+  const R d00 = tp.p10.x - v000, d01 = tp.p10.y - v001;   // x-differences of the four (y,z) edges
+  const R d10 = tp.p11.x - v010, d11 = tp.p11.y - v011;
+  const R v00 = gfma(dx, d00, v000), v01 = gfma(dx, d01, v001);   // :221-224
+  const R v10 = gfma(dx, d10, v010), v11 = gfma(dx, d11, v011);
+  const R e0 = v10 - v00, e1 = v11 - v01;                          // y-differences
+  const R v0 = gfma(dy, e0, v00), v1 = gfma(dy, e1, v01);          // :226-227
+  const R dd = v1 - v0;                                            // z-difference (:231)
+  const R dist = gfma(dze, dd, v0);                                // :229
+  gy = gfma(dze, e1 - e0, e0);                                     // :232-233
+  const R h0 = gfma(dy, d10 - d00, d00), h1 = gfma(dy, d11 - d01, d01);
+  gx = gfma(dze, h1 - h0, h0);                                     // :234-239
+  gz = tp.zflat ? (R)0 : dd;
   is_out = tp.out;
   return tp.out ? (R)-1 : dist;   // the caller zeroes the gradient's weight when out (grad := 0)
 }
@@ -346,22 +342,18 @@ __device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 
   const f2 v010 = {p01[0].x, p01[1].x}, v011 = {p01[0].y, p01[1].y};
   const f2 v100 = {p10[0].x, p10[1].x}, v101 = {p10[0].y, p10[1].y};
   const f2 v110 = {p11[0].x, p11[1].x}, v111 = {p11[0].y, p11[1].y};
-  const f2 one = splat(1.0f);
-  const f2 ex = one - dx, ey = one - dy, ez = one - dz;
-  const f2 v00 = ex * v000 + dx * v100;  // :221-224
-  const f2 v01 = ex * v001 + dx * v101;
-  const f2 v10 = ex * v010 + dx * v110;
-  const f2 v11 = ex * v011 + dx * v111;
-  const f2 v0 = ey * v00 + dy * v10;     // :226-227
-  const f2 v1 = ey * v01 + dy * v11;
-  f2 dist = ez * v0 + dz * v1;           // :229
-  gz = (v1 - v0) * rinv;                 // :231
-  gy = (ez * (v10 - v00) + dz * (v11 - v01)) * rinv;  // :232-233
-  f2 g0 = ez * ey * (v100 - v000);       // :234-239
-  g0 += ez * dy * (v110 - v010);
-  g0 += dz * ey * (v101 - v001);
-  g0 += dz * dy * (v111 - v011);
-  gx = g0 * rinv;
+  // difference form, gradient unscaled (per voxel): see sdf_blend
+  const f2 d00 = v100 - v000, d01 = v101 - v001, d10 = v110 - v010, d11 = v111 - v011;
+  const f2 v00 = pk_fma(dx, d00, v000), v01 = pk_fma(dx, d01, v001);   // :221-224
+  const f2 v10 = pk_fma(dx, d10, v010), v11 = pk_fma(dx, d11, v011);
+  const f2 e0 = v10 - v00, e1 = v11 - v01;
+  const f2 v0 = pk_fma(dy, e0, v00), v1 = pk_fma(dy, e1, v01);         // :226-227
+  const f2 dd = v1 - v0;                                               // :231
+  f2 dist = pk_fma(dz, dd, v0);                                        // :229
+  gy = pk_fma(dz, e1 - e0, e0);                                        // :232-233
+  const f2 h0 = pk_fma(dy, d10 - d00, d00), h1 = pk_fma(dy, d11 - d01, d01);
+  gx = pk_fma(dz, h1 - h0, h0);                                        // :234-239
+  gz = dd;
   if (zflat[0]) gz.x = 0.0f;
   if (zflat[1]) gz.y = 0.0f;
   return dist;
@@ -398,7 +390,7 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
   const f2 cd = splat(a.alpha) * e;                // :509
   const f2 gd = splat(-a.alpha_over_r) * e;        // :514
   f2 csum = splat(wdt) * (cd * vn);                // :373
-  f2 f1 = splat(wdt) * (gd * cd * vn);
+  f2 f1 = splat(wdt * a.res_inv) * (gd * cd * vn);   // 1/res: g3 is per voxel
   const f2 f2_ = splat(wdt) * (cd * ivn);
   if (outA) f1.x = 0.0f;
   if (outB) f1.y = 0.0f;
@@ -687,7 +679,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
           const R ivn = quick_rcp(vn);
           R g3[3];
           bool is_out;
-          const R dist = sdf_blend(a, taps[c], g3[0], g3[1], g3[2], is_out);
+          const R dist = sdf_blend(taps[c], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
           // samples past the loop bound of :353 and idle lanes contribute nothing:
           // every term below carries a factor e
           const R e = live ? penalty_exp((a.d0 - dist) * a.inv_r) : (R)0;   // exp(-(d - d0)/r)
@@ -695,7 +687,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
           const R gd = -a.alpha_over_r * e;            // :514
           R csum = wdt * (cd * vn);                    // :373, weighted as in :417-418
           // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
-          const R f1 = is_out ? (R)0 : wdt * (gd * cd * vn), f2 = wdt * (cd * ivn);
+          const R f1 = is_out ? (R)0 : (wdt * a.res_inv) * (gd * cd * vn), f2 = wdt * (cd * ivn);   // 1/res: g3's unit
           R w1[3], w2[3], w3[3];
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
