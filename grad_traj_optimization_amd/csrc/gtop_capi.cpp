@@ -34,9 +34,9 @@ struct gtop_ctx {
 
   // ESDF construction workspace
   uint8_t *occ = nullptr;
-  int *tmp1 = nullptr, *tmp2 = nullptr;
+  int *tmp1 = nullptr, *tmp2 = nullptr, *rows = nullptr;
   double *d_pts = nullptr;
-  size_t cap_occ = 0, cap_tmp1 = 0, cap_tmp2 = 0, pts_cap = 0;
+  size_t cap_occ = 0, cap_tmp1 = 0, cap_tmp2 = 0, cap_rows = 0, pts_cap = 0;
 
   // problem set by gtop_set_problem
   int B = 0, m = 0, t_stride = 0;
@@ -246,7 +246,7 @@ int gtop_destroy(gtop_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   release_sdf(c);
-  void *bufs[] = {c->occ, c->tmp1, c->tmp2, c->d_pts,
+  void *bufs[] = {c->occ, c->tmp1, c->tmp2, c->rows, c->d_pts,
                   c->d_T, c->d_Df, c->d_x, c->d_cost, c->d_grad,
                   c->mma_vec, c->mma_scal, c->mma_int, c->mma_f, c->mma_g, c->mma_lb, c->mma_ub};
   for (void *p : bufs)
@@ -332,6 +332,7 @@ int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
   int rc;
   if ((rc = ensure(c, &c->tmp1, &c->cap_tmp1, nvox))) return rc;
   if ((rc = ensure(c, &c->tmp2, &c->cap_tmp2, nvox))) return rc;
+  if ((rc = ensure(c, &c->rows, &c->cap_rows, gtop_esdf_rows_ints(g)))) return rc;
   if (!gtop_esdf_supported(g))
     return fail(c, GTOP_ERR_INVALID, "updateSDFMap: grid too large for the device builder (nz <= 4096, nx, ny <= 32768)");
   if (npts > 0) {
@@ -340,7 +341,7 @@ int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
   }
   HIPCHK(c, gtop_launch_esdf_reset(c->occ, c->sdf64, nvox, c->stream));            // resetBuffer
   HIPCHK(c, gtop_launch_esdf_mark(g, c->d_pts, npts, c->occ, c->stream));         // setOccupancy
-  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->sdf64, c->sdf32, c->stream));   // updateESDF3d
+  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, c->sdf32, c->stream));   // updateESDF3d
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 }

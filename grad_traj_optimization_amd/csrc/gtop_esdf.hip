@@ -15,12 +15,18 @@
 //             nearest occupied voxel of the column)^2 — found with wave
 //             ballots (one 64-bit mask per 64 voxels of the column) and
 //             clz/ctz, no search loop;
-//   y, x    : outward scan v = q, q±1, q±2, ... with the exact cut-off
-//             d^2 >= best (in(v) >= 0), neighbouring lanes on neighbouring z
-//             so every step is a coalesced row; 8 (y) / 4 (x) steps are read per
-//             round trip — the scan is latency-bound, not bandwidth-bound;
-//   x sweep : also the final res*sqrt(.) (exactly rounded fp64, as the
-//             reference's) and the fp32 copy used by the GTOP_F32 path.
+//   y sweep : after the z sweep a voxel of line (x, ., z) is finite exactly when its
+//             (x,y) column holds an obstacle, whatever z — so every row x has ONE
+//             sorted list of candidate columns (built by esdf_rows_kernel with
+//             ballots/popcounts).  A voxel walks that list outward from its own y,
+//             four candidates per round trip, with the exact cut-off d^2 >= best;
+//             obstacle-free stretches cost nothing;
+//   x sweep : outward scan v = q, q±1, q±2, ... with the same cut-off (in(v) >= 0),
+//             neighbouring lanes on neighbouring z so every step is a coalesced
+//             row, 4 steps per round trip — the scan is latency-bound, not
+//             bandwidth-bound;
+//             it also applies the final res*sqrt(.) (exactly rounded fp64, as the
+//             reference's) and writes the fp32 copy used by the GTOP_F32 path.
 // Result: bit-identical to the CPU restatement and to scipy's exact EDT
 // (tests), HBM/latency-bound integer work, no scratch workspace.  (An LDS-tiled
 // variant of the y/x scans was measured 4-6x SLOWER: 3 200 long-running
@@ -66,19 +72,23 @@ esdf_mark_kernel(const GtopGrid g, const double *__restrict__ pts, int npts,
 constexpr int kMaxChunks = 64;   // columns up to 4096 voxels
 
 __global__ void __launch_bounds__(256)
-esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out) {
+esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out,
+              uint8_t *__restrict__ colany) {
   __shared__ unsigned long long masks[4][kMaxChunks];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t ncol = (size_t)g.nx * g.ny;
   const int nz = g.nz, nchunk = (nz + 63) >> 6;
   for (size_t col = (size_t)blockIdx.x * 4 + w; col < ncol; col += (size_t)gridDim.x * 4) {
     const uint8_t *c = occ + col * nz;
+    unsigned long long any = 0ull;
     for (int k = 0; k < nchunk; ++k) {
       const int z = k * 64 + lane;
       const bool o = (z < nz) && (c[z] == 1);
       const unsigned long long mk = __ballot(o);
       if (lane == 0) masks[w][k] = mk;
+      any |= mk;
     }
+    if (lane == 0) colany[col] = any != 0ull;   // the column holds an obstacle: finite for the y sweep
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int ko = 0; ko < nchunk; ++ko) {
@@ -107,37 +117,104 @@ esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict
   }
 }
 
-// y sweep (PASS 1, sdf_map.cpp:328-346) and x sweep (PASS 2, :348-364): one lane
-// per voxel, lanes along z.  out(q) = min_v ((q-v)^2 + in(v)), scanning outward.
-template <int PASS>
+// Candidate columns of every row x for the y sweep: cols[x][0..cnt[x]) = the y of the
+// columns that hold an obstacle, ascending; rank[x][y] = number of them below y
+// (= index of the first candidate at or above y).  One wavefront per row.
+__global__ void __launch_bounds__(64)
+esdf_rows_kernel(const GtopGrid g, const uint8_t *__restrict__ colany, int *__restrict__ cols,
+                 int *__restrict__ rank, int *__restrict__ cnt) {
+  const int lane = threadIdx.x, ny = g.ny;
+  for (int x = blockIdx.x; x < g.nx; x += gridDim.x) {
+    int base = 0;
+    for (int y0 = 0; y0 < ny; y0 += 64) {
+      const int y = y0 + lane;
+      const bool f = (y < ny) && colany[(size_t)x * ny + y];
+      const unsigned long long mk = __ballot(f);
+      const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
+      if (y < ny) rank[(size_t)x * ny + y] = pos;
+      if (f) cols[(size_t)x * ny + pos] = y;
+      base += __popcll(mk);
+    }
+    if (lane == 0) cnt[x] = base;
+  }
+}
+
+// y sweep (sdf_map.cpp:328-346): out(x,y,z) = min over candidate columns v of (y-v)^2 + in(x,v,z).
 __global__ void __launch_bounds__(256)
-esdf_scan_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ fout,
-                 double *__restrict__ dist, float *__restrict__ dist32) {
+esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ fout, const int *__restrict__ cols,
+              const int *__restrict__ rank, const int *__restrict__ cnt) {
+  constexpr int U = 4;   // candidates per round trip and side
   const size_t nvox = (size_t)g.nx * g.ny * g.nz;
   const size_t nyz = (size_t)g.ny * g.nz;
+  const int ny = g.ny, nz = g.nz;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (size_t)gridDim.x * blockDim.x) {
     const int x = (int)(i / nyz);
     const size_t r = i - (size_t)x * nyz;
-    const int y = (int)(r / g.nz);
-    const int q = PASS == 1 ? y : x;
-    const int n = PASS == 1 ? g.ny : g.nx;
-    const size_t stride = PASS == 1 ? (size_t)g.nz : nyz;
-    const int *line = fin + (i - (size_t)q * stride);
-    constexpr int kScanBatch = PASS == 1 ? 8 : 4;
-    int best = line[(size_t)q * stride];
+    const int q = (int)(r / nz);
+    const int *line = fin + (i - (size_t)q * nz);   // (x, 0, z)
+    const int *cx = cols + (size_t)x * ny;
+    const int c = cnt[x];
+    int best = fin[i];
+    const int k0 = rank[(size_t)x * ny + q];        // first candidate at or above q
+    // below q: candidates k0-1, k0-2, ... (descending y, ascending distance)
+    for (int k = k0 - 1; k >= 0; k -= U) {
+      const int d0 = q - cx[k];
+      if (d0 * d0 >= best) break;   // in(v) >= 0: nothing farther can win
+      int v[U], f[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (k - u >= 0) ? cx[k - u] : -1;
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = (v[u] >= 0) ? line[(size_t)v[u] * nz] : kInf;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int d = q - v[u];
+        const int cand = (v[u] >= 0) ? d * d + f[u] : kInf;   // d <= 2^15, f <= kInf: below 2^31
+        best = cand < best ? cand : best;
+      }
+    }
+    // above q (the voxel's own column, if it is a candidate, is `best` already)
+    for (int k = k0 + ((k0 < c && cx[k0] == q) ? 1 : 0); k < c; k += U) {
+      const int d0 = cx[k] - q;
+      if (d0 * d0 >= best) break;
+      int v[U], f[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (k + u < c) ? cx[k + u] : -1;
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = (v[u] >= 0) ? line[(size_t)v[u] * nz] : kInf;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int d = v[u] - q;
+        const int cand = (v[u] >= 0) ? d * d + f[u] : kInf;
+        best = cand < best ? cand : best;
+      }
+    }
+    fout[i] = best > kInf ? kInf : best;
+  }
+}
+
+// x sweep (sdf_map.cpp:348-364): one lane per voxel, lanes along z.
+// out(q) = min_v ((q-v)^2 + in(v)), scanning outward; then dist = min(res*sqrt(out), previous).
+__global__ void __launch_bounds__(256)
+esdf_x_kernel(const GtopGrid g, const int *__restrict__ fin, double *__restrict__ dist, float *__restrict__ dist32) {
+  constexpr int kScanBatch = 4;   // steps per round trip (4 beats 8 and 16 at 400^3; profiles/r1/esdf_kernels.txt)
+  const size_t nvox = (size_t)g.nx * g.ny * g.nz;
+  const size_t nyz = (size_t)g.ny * g.nz;
+  const int n = g.nx;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i / nyz);
+    const int *line = fin + (i - (size_t)q * nyz);
+    int best = line[(size_t)q * nyz];
     const int reach = q > n - 1 - q ? q : n - 1 - q;
-    // kScanBatch steps of the outward scan per round trip (8 along y, where most lines start
-    // with long obstacle-free runs; 4 along x — measured, profiles/r1/esdf_kernels.txt): the loads of a batch are
-    // independent and issue together; entries past the exact cut-off d^2 >= best
-    // cannot win (in(v) >= 0), so reading a few of them changes nothing.
+    // The loads of a batch are independent and issue together; entries past the exact
+    // cut-off d^2 >= best cannot win (in(v) >= 0), so reading a few of them changes nothing.
     for (int d0 = 1; d0 <= reach; d0 += kScanBatch) {
       if (d0 * d0 >= best) break;
       int lo[kScanBatch], hi[kScanBatch];
 #pragma unroll
       for (int u = 0; u < kScanBatch; ++u) {
         const int d = d0 + u;
-        lo[u] = (q - d >= 0) ? line[(size_t)(q - d) * stride] : kInf;
-        hi[u] = (q + d < n) ? line[(size_t)(q + d) * stride] : kInf;
+        lo[u] = (q - d >= 0) ? line[(size_t)(q - d) * nyz] : kInf;
+        hi[u] = (q + d < n) ? line[(size_t)(q + d) * nyz] : kInf;
       }
 #pragma unroll
       for (int u = 0; u < kScanBatch; ++u) {
@@ -147,20 +224,15 @@ esdf_scan_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict_
         best = c < best ? c : best;
       }
     }
-    if (best > kInf) best = kInf;
-    if (PASS == 1) {
-      fout[i] = best;
-    } else {
-      // sdf_map.cpp:355-361: min(res*sqrt(val), previous) with previous = 10000 after the
-      // reset; a line without obstacles carries DBL_MAX there, i.e. keeps the 10000
-      double dv = 10000.0;
-      if (best < kInf) {
-        const double e = g.res * sqrt((double)best);
-        dv = e < dv ? e : dv;
-      }
-      dist[i] = dv;
-      dist32[i] = (float)dv;
+    // sdf_map.cpp:355-361: min(res*sqrt(val), previous) with previous = 10000 after the
+    // reset; a line without obstacles carries DBL_MAX there, i.e. keeps the 10000
+    double dv = 10000.0;
+    if (best < kInf) {
+      const double e = g.res * sqrt((double)best);
+      dv = e < dv ? e : dv;
     }
+    dist[i] = dv;
+    dist32[i] = (float)dv;
   }
 }
 
@@ -182,19 +254,29 @@ bool gtop_esdf_supported(const GtopGrid &g) {
   return g.nz <= 64 * kMaxChunks && g.nx <= 32768 && g.ny <= 32768;
 }
 
-hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, double *dist,
-                                  float *dist32, hipStream_t stream) {
+size_t gtop_esdf_rows_ints(const GtopGrid &g) {
+  const size_t ncol = (size_t)g.nx * g.ny;
+  return 2 * ncol + (size_t)g.nx + (ncol + 3) / 4;   // cols, rank, cnt, colany (bytes)
+}
+
+hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,
+                                  double *dist, float *dist32, hipStream_t stream) {
   const size_t ncol = (size_t)g.nx * g.ny, nvox = ncol * g.nz;
+  int *cols = rows, *rank = rows + ncol, *cnt = rows + 2 * ncol;
+  uint8_t *colany = reinterpret_cast<uint8_t *>(rows + 2 * ncol + g.nx);
   const unsigned zblocks = (unsigned)((ncol + 3) / 4 < 65536 ? (ncol + 3) / 4 : 65536);
-  hipLaunchKernelGGL(esdf_z_kernel, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1);
+  hipLaunchKernelGGL(esdf_z_kernel, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const unsigned vblocks = (unsigned)((nvox + 255) / 256 < (1u << 20) ? (nvox + 255) / 256 : (1u << 20));
-  hipLaunchKernelGGL(esdf_scan_kernel<1>, dim3(vblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2,
-                     (double *)nullptr, (float *)nullptr);
+  hipLaunchKernelGGL(esdf_rows_kernel, dim3(g.nx < 65536 ? g.nx : 65536), dim3(64), 0, stream, g,
+                     (const uint8_t *)colany, cols, rank, cnt);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(esdf_scan_kernel<2>, dim3(vblocks), dim3(256), 0, stream, g, (const int *)tmp2, (int *)nullptr,
-                     dist, dist32);
+  const unsigned vblocks = (unsigned)((nvox + 255) / 256 < (1u << 20) ? (nvox + 255) / 256 : (1u << 20));
+  hipLaunchKernelGGL(esdf_y_kernel, dim3(vblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2,
+                     (const int *)cols, (const int *)rank, (const int *)cnt);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(esdf_x_kernel, dim3(vblocks), dim3(256), 0, stream, g, (const int *)tmp2, dist, dist32);
   return hipGetLastError();
 }

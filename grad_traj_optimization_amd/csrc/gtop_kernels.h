@@ -66,8 +66,9 @@ hipError_t gtop_launch_esdf_mark(const GtopGrid &g, const double *pts, int npts,
 // updateESDF3d (sdf_map.cpp:310-368): the three sweeps z, y, x as exact integer minimisations,
 // then res*sqrt(.) into dist (fp64) and dist32 (fp32 copy).  tmp1/tmp2: nvox int32 each.
 bool gtop_esdf_supported(const GtopGrid &g);
-hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, double *dist,
-                                  float *dist32, hipStream_t stream);
+size_t gtop_esdf_rows_ints(const GtopGrid &g);   // ints of row workspace the builder needs
+hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,
+                                  double *dist, float *dist32, hipStream_t stream);
 
 // fused: cost/gradient at st.xcur + MMA update in one launch (fp64; spl must be 1, 3 or 6)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
