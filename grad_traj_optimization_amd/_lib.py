@@ -209,8 +209,11 @@ class GtopContext:
         self._chk(self._L.gtop_set_problem(self._h, B, m, _p(T), stride, _p(Df)))
         self.B, self.m = B, m
 
-    def set_optimizer_fusion(self, fused=True):
-        self._chk(self._L.gtop_set_optimizer_fusion(self._h, int(bool(fused))))
+    def set_optimizer_fusion(self, mode=2):
+        """2 (or True): whole optimizer loop in one launch; 1: MMA update fused into the
+        evaluation kernel, one launch per iteration; 0 (or False): separate update launch."""
+        mode = 2 if mode is True else int(mode)
+        self._chk(self._L.gtop_set_optimizer_fusion(self._h, mode))
 
     def set_launch_geometry(self, waves=0, samples_per_lane=0):
         self._chk(self._L.gtop_set_launch_geometry(self._h, int(waves), int(samples_per_lane)))

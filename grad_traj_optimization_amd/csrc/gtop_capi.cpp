@@ -53,7 +53,8 @@ struct gtop_ctx {
 
   int waves = 0;   // 0 = auto
   int spl = 0;     // samples per lane, 0 = auto
-  bool fuse_mma = true;     // optimizer: MMA update fused into the evaluation kernel (tuning/debug knob)
+  int fuse_mma = 2;         // optimizer: 0 separate update launch, 1 update fused into the evaluation kernel,
+                            //            2 (default) the whole loop in one launch (tuning/debug knob)
   int auto_spl_small = 3;   // what auto picks for B < 4096 (m = 6: one wavefront per trajectory)
   int auto_spl_large = 6;   // what auto picks for B >= 4096 (m = 6: two trajectories per wavefront)
 
@@ -584,8 +585,10 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
   HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
   int waves, spl, tpb;
   launch_geometry(c, B, m, &waves, &spl, &tpb);
-  const bool fused = c->fuse_mma && (spl == 1 || spl == 3 || spl == 6);
-  for (int it = 0; it < max_evals; ++it) {
+  const bool fused = c->fuse_mma != 0 && (spl == 1 || spl == 3 || spl == 6);
+  const bool resident = fused && c->fuse_mma == 2;   // one launch runs all max_evals evaluations of every trajectory
+  st.iters = resident ? max_evals : 1;
+  for (int it = 0; it < (resident ? 1 : max_evals); ++it) {
     if (fused) {
       // one launch per iteration: the evaluation kernel runs the MMA update as its epilogue
       GtopKernelArgs<double> a;
@@ -698,7 +701,8 @@ int gtop_clear_cost_curve(gtop_ctx *c) {
 
 int gtop_set_optimizer_fusion(gtop_ctx *c, int fused) {
   if (!c) return GTOP_ERR_INVALID;
-  c->fuse_mma = fused != 0;
+  if (fused < 0 || fused > 2) return fail(c, GTOP_ERR_INVALID, "optimizer fusion mode is 0, 1 or 2");
+  c->fuse_mma = fused;
   return GTOP_OK;
 }
 

@@ -38,6 +38,7 @@ struct GtopMmaState {
   const double *lb, *ub;                                  // [B][n]
   double *rho, *minf, *gval, *wval;                       // [B]
   int *k, *state;                                         // [B]
+  int iters;                                              // evaluations per launch of the fused kernel
 };
 size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem);
 

@@ -457,12 +457,12 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
 // Register budget (waves per SIMD the compiler must leave room for).  fp64: the
 // rolled sample loops (SPL >= 5, the large-batch geometries) fit 168 VGPRs = 3
 // waves per SIMD without spilling; the unrolled small-batch bodies need ~210 and
-// the optional velocity/acceleration block (DYN) more.  fp32: 3 waves; the
+// the optional velocity/acceleration block (DYN) and the optimizer epilogue (MMA) more.  fp32: 3 waves; the
 // 128-VGPR budget of 4 waves spills.
-template <typename R, int SPL, bool DYN> struct MinWaves {
-  static constexpr int v = (!DYN && (SPL == 5 || SPL == 6)) ? GTOP_F64_MIN_WAVES_ROLLED : GTOP_F64_MIN_WAVES;
+template <typename R, int SPL, bool DYN, bool MMA> struct MinWaves {
+  static constexpr int v = (!DYN && !MMA && (SPL == 5 || SPL == 6)) ? GTOP_F64_MIN_WAVES_ROLLED : GTOP_F64_MIN_WAVES;
 };
-template <int SPL, bool DYN> struct MinWaves<float, SPL, DYN> { static constexpr int v = DYN ? 2 : GTOP_F32_MIN_WAVES; };
+template <int SPL, bool DYN, bool MMA> struct MinWaves<float, SPL, DYN, MMA> { static constexpr int v = DYN ? 2 : GTOP_F32_MIN_WAVES; };
 
 //
 // MMA = true (fp64 only) appends the optimizer step: `a.x` is then the trial
@@ -470,7 +470,7 @@ template <int SPL, bool DYN> struct MinWaves<float, SPL, DYN> { static constexpr
 // a trajectory are known the same workgroup runs its MMA update
 // (gtop_mma_update_trajectory) — one launch per optimizer iteration.
 template <typename R, bool DYN, int SPL, bool MMA, bool WIDE>
-__global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R, SPL, DYN>::v)) GTOP_WAVES_PER_EU_ATTR
+__global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R, SPL, DYN, MMA>::v)) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront
@@ -514,6 +514,13 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
     const int grp = (vb & 7) * per_xcd + (vb >> 3);
     if (grp >= ngroups) continue;      // block-uniform
     const int b0 = grp * TPB;
+    // MMA: the trajectories of a group are independent of every other group, so the whole
+    // optimizer loop of the group runs here — evaluate at xcur, update, evaluate again —
+    // with st.iters evaluations per launch.  What one wavefront of the workgroup writes
+    // (xcur and the MMA state) the next pass reads after a workgroup barrier; the CU's
+    // vector L1 is shared by the workgroup, so that needs no cache maintenance.
+    const int npass = MMA ? st.iters : 1;
+    for (int pass = 0; pass < npass; ++pass) {
     GTOP_STAMP(0);
     const int ntraj = min(TPB, a.B - b0);   // trajectories this pass
     const int nseg = ntraj * m;             // live virtual segments
@@ -847,8 +854,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
         const R *gs = gseg + tl * m * 18;
         const R v = gs[((wpt - 1) * 3 + axis) * 6 + 2 * der + 1] +   // end of segment wpt-1
                     gs[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
-        gb[q] = v + (R)1e-5;
-        if (MMA) gl[q] = v + (R)1e-5;
+        if (MMA) gl[q] = v + (R)1e-5;   // consumed by the update below; nothing leaves the chip
+        else gb[q] = v + (R)1e-5;
       }
 #ifdef GTOP_STAMPS
       GTOP_STAMP(13);
@@ -859,8 +866,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
         for (int i = lane; i < m; i += 64) part += ccol[tl * m + i];
         part = wave_sum(part);
         if (lane == 0) {
-          a.cost[b0 + tl] = part + (R)1e-3;
           if (MMA) fc[tl] = part + (R)1e-3;
+          else a.cost[b0 + tl] = part + (R)1e-3;
         }
       }
       if constexpr (MMA) {
@@ -870,7 +877,8 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
       }
     }
     GTOP_STAMP(6);
-    __syncthreads();   // LDS is reused by the next group of this block
+    __syncthreads();   // LDS is reused by the next pass / the next group of this block
+    }
   }
 }
 

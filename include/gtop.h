@@ -231,9 +231,11 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
  * fit).  0 = choose from B and m.  Results do not depend on it beyond fp
  * summation order. */
 int gtop_set_launch_geometry(gtop_ctx *ctx, int waves, int samples_per_lane);
-/* Batched optimizer: 1 (default) = the MMA update runs as the epilogue of the
- * evaluation kernel (one launch per iteration); 0 = separate update launch.
- * Same arithmetic either way. */
+/* Batched optimizer: 2 (default) = one launch runs the whole loop (evaluate,
+ * MMA update, evaluate, ... max_evals times) for every trajectory — they are
+ * independent, so nothing has to return to the host or to HBM in between;
+ * 1 = the MMA update runs as the epilogue of the evaluation kernel, one launch
+ * per iteration; 0 = separate update launch.  Same arithmetic in all three. */
 int gtop_set_optimizer_fusion(gtop_ctx *ctx, int fused);
 
 #ifdef __cplusplus

@@ -150,8 +150,9 @@ def test_optimize_device_api_and_determinism(scene, gtop):
 
 @pytest.mark.parametrize("B,m", [(64, 6), (5000, 6), (300, 12)])
 def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m):
-    """The MMA update as the evaluation kernel's epilogue (one launch per iteration)
-    does the same arithmetic as the two-launch form: bit-identical results."""
+    """Three ways to run the same loop — the whole loop in one launch (default), the MMA
+    update as the evaluation kernel's epilogue with one launch per iteration, and the
+    two-launch form — do the same arithmetic: bit-identical results."""
     import torch
     mp, ctx, sdf = scene
     b = problem.make_trajectories(B, m, mp, seed=900 + m)
@@ -162,11 +163,12 @@ def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m):
     lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
     ctx.set_params()
     res = []
-    for fused in (True, False):
-        ctx.set_optimizer_fusion(fused)
+    for mode in (2, 1, 0):
+        ctx.set_optimizer_fusion(mode)
         x = torch.tensor(b.x, device=dev)
         x, c = ctx.optimize_device(x, Df, T, lbt, ubt, 15)
         torch.cuda.synchronize()
         res.append((x.clone(), c.clone()))
-    ctx.set_optimizer_fusion(True)
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    ctx.set_optimizer_fusion(2)
+    for r in res[1:]:
+        assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1])
