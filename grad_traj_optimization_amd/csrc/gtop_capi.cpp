@@ -554,8 +554,9 @@ int gtop_trajectory_stats(gtop_ctx *c, int B, const double *x, double dt_sample,
   return GTOP_OK;
 }
 
-// Batched optimizer: max_evals lock-step iterations of {cost/gradient kernel,
-// MMA update kernel} on `stream`; no host synchronisation inside.
+// Batched optimizer: max_evals rounds of {cost/gradient, MMA update} per trajectory on
+// `stream` — one launch for the whole loop (fusion mode 2), one per round (1), or two
+// per round (0); no host synchronisation inside.
 int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df, const void *d_T,
                          int time_stride, const void *d_lb, const void *d_ub, int max_evals, void *d_minf,
                          void *hip_stream) {

@@ -466,9 +466,9 @@ template <int SPL, bool DYN, bool MMA> struct MinWaves<float, SPL, DYN, MMA> { s
 
 //
 // MMA = true (fp64 only) appends the optimizer step: `a.x` is then the trial
-// point st.xcur of the lock-step CCSA-MMA driver, and after cost and gradient of
+// point st.xcur of the batched CCSA-MMA driver, and after cost and gradient of
 // a trajectory are known the same workgroup runs its MMA update
-// (gtop_mma_update_trajectory) — one launch per optimizer iteration.
+// (gtop_mma_update_trajectory) and — st.iters times in all — evaluates again.
 template <typename R, bool DYN, int SPL, bool MMA, bool WIDE>
 __global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R, SPL, DYN, MMA>::v)) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {

@@ -1,4 +1,4 @@
-// gtop_mma.hip — lock-step batched CCSA-MMA update on gfx950.
+// gtop_mma.hip — batched CCSA-MMA update on gfx950 (stand-alone launch form).
 //
 // Replaces, for B independent problems at once, the optimizer loop that the
 // reference runs one problem at a time through NLopt LD_MMA

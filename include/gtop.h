@@ -166,11 +166,12 @@ int gtop_eval_device(gtop_ctx *ctx, int dtype, int B, int m, const void *d_x,
 int gtop_default_bounds(int B, int m, const double *path, double bos,
                         double vos, double aos, double *lb, double *ub);
 
-/* B independent bound-constrained CCSA-MMA solves in lock step on the device:
- * what B calls of nlopt::opt::optimize with algorithm 24 (LD_MMA) do one
- * after another in the reference (src/grad_traj_optimizer.cpp:137-195), here
- * as max_evals rounds of {cost/gradient kernel, optimizer update kernel}.  The
- * stop rule is an evaluation count (the reference stops on wall-clock
+/* B independent bound-constrained CCSA-MMA solves on the device: what B calls
+ * of nlopt::opt::optimize with algorithm 24 (LD_MMA) do one after another in
+ * the reference (src/grad_traj_optimizer.cpp:137-195), here as max_evals
+ * rounds of {cost/gradient, optimizer update} per trajectory — by default all
+ * of them inside one kernel launch (gtop_set_optimizer_fusion).  The stop rule
+ * is an evaluation count (the reference stops on wall-clock
  * maxtime, :144-148, which is not reproducible).  x: in = start point
  * (:182-187), out = best point found; min_cost: its cost.  fp64.
  * gtop_optimize_batch uses the problem of gtop_set_problem and host buffers;
