@@ -146,9 +146,9 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
 // profiles/r1/sweep_geometry_v4.txt): B >= 4096 -> spl 6 (two 20-control-point
 // trajectories per wavefront, amortising the few-lane phases); smaller batches
 // -> spl 3 (one wavefront per trajectory: more wavefronts in flight).
-void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb) {
+void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb, int auto_spl = 0) {
   int s = c->spl;
-  if (s == 0) s = (B >= 4096) ? c->auto_spl_large : c->auto_spl_small;
+  if (s == 0) s = auto_spl ? auto_spl : ((B >= 4096) ? c->auto_spl_large : c->auto_spl_small);
   const int spw = gtop_eval_segments_per_wave(s);
   int w = c->waves > 0 ? c->waves : (spw >= m ? 1 : (m + spw - 1) / spw);
   if (w < 1) w = 1;
@@ -585,7 +585,9 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
   st.k = c->mma_int; st.state = st.k + B;
   HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
   int waves, spl, tpb;
-  launch_geometry(c, B, m, &waves, &spl, &tpb);
+  // whole loop in one launch: the unrolled one-trajectory-per-wavefront body wins at every batch
+  // size (measured 1024 ... 16384, tools/opt_time.py); otherwise the evaluation kernel's own rule
+  launch_geometry(c, B, m, &waves, &spl, &tpb, c->fuse_mma == 2 ? c->auto_spl_small : 0);
   const bool fused = c->fuse_mma != 0 && (spl == 1 || spl == 3 || spl == 6);
   const bool resident = fused && c->fuse_mma == 2;   // one launch runs all max_evals evaluations of every trajectory
   st.iters = resident ? max_evals : 1;

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Diagnostic: wall time of gtop_optimize_device for launch geometries and fusion modes.
+usage: tools/opt_time.py [B ...]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.getcwd())
+import grad_traj_optimization_amd as gtop
+from grad_traj_optimization_amd import problem
+
+mp = problem.make_map(200, density=0.02, seed=0)
+ctx = gtop.GtopContext(0)
+ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+ctx.update_sdf_map(mp.obstacle_points())
+ctx.set_params()
+dev = torch.device("cuda:0")
+for B in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384]:
+    b = problem.make_trajectories(B, 6, mp, seed=1)
+    perm = problem.spatial_order(b.waypoints, mp.origin, mp.map_size)
+    b = problem.permute(b, perm)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    Df = torch.tensor(b.Df.reshape(-1, 18), device=dev)
+    T = torch.tensor(b.T, device=dev)
+    lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
+    x0 = torch.tensor(b.x, device=dev)
+    for spl in (0, 1, 3, 6):
+        for mode in (2, 1):
+            ctx.set_launch_geometry(0, spl)
+            ctx.set_optimizer_fusion(mode)
+            ts = []
+            for evals in (50, 100):
+                x = x0.clone()
+                ctx.optimize_device(x, Df, T, lbt, ubt, evals)
+                torch.cuda.synchronize()
+                x = x0.clone()
+                t0 = time.perf_counter()
+                ctx.optimize_device(x, Df, T, lbt, ubt, evals)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            print(f"B={B} spl={spl} mode={mode}: 50 evals {ts[0]*1e3:.3f} ms, 100 evals {ts[1]*1e3:.3f} ms, "
+                  f"slope {(ts[1]-ts[0])/50*1e6:.2f} us/eval-round", flush=True)
