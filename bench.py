@@ -199,7 +199,8 @@ def main():
             graphs = []
             for j in range(2):
                 gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph):
+                # thread_local: a HIP call from another thread (RCCL's watchdog) must not break the capture
+                with torch.cuda.graph(gph, capture_error_mode="thread_local"):
                     run_bucket_eager(j)
                 graphs.append(gph)
             pipe.run_bucket_fn = run_bucket_graph
