@@ -97,6 +97,9 @@ def load_library():
         "gtop_coefficients_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]),
         "gtop_eval_trajectories_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp]),
         "gtop_trajectory_stats": (C.c_int, [vp, C.c_int, dp, C.c_double, dp, dp]),
+        "gtop_set_moving_boxes": (C.c_int, [vp, C.c_int, dp, dp, dp]),
+        "gtop_edt_query_device": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp]),
+        "gtop_edt_query": (C.c_int, [vp, C.c_int, dp, dp, dp, dp]),
         "gtop_default_bounds": (C.c_int, [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_double, dp, dp]),
         "gtop_optimize_batch": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, dp]),
         "gtop_optimize_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]),
@@ -291,6 +294,36 @@ class GtopContext:
         stats = np.empty((B, len(self.TRAJ_STATS)))
         self._chk(self._L.gtop_trajectory_stats(self._h, B, _p(x), float(dt_sample), _p(coeff), _p(stats)))
         return coeff, stats
+
+    # -- static field + moving boxes (EDTEnvironment) --
+    def set_moving_boxes(self, p0, vel, scale):
+        """Boxes {p0, vel, scale}, each (nbox, 3): centre p0 + vel*t, extent +-scale/2."""
+        p0, vel, scale = (_f64(a).reshape(-1, 3) for a in (p0, vel, scale))
+        assert p0.shape == vel.shape == scale.shape
+        self._chk(self._L.gtop_set_moving_boxes(self._h, p0.shape[0], _p(p0), _p(vel), _p(scale)))
+
+    def edt_query(self, pos, time):
+        """(dist (N,), grad (N, 3)) at pos (N, 3), time (N,); time < 0 = static field only."""
+        pos = _f64(pos).reshape(-1, 3)
+        time = _f64(np.broadcast_to(time, (pos.shape[0],)))
+        dist = np.empty(pos.shape[0])
+        grad = np.empty((pos.shape[0], 3))
+        self._chk(self._L.gtop_edt_query(self._h, pos.shape[0], _p(pos), _p(time), _p(dist), _p(grad)))
+        return dist, grad
+
+    def edt_query_device(self, pos, time, stream=None):
+        """torch fp64 CUDA tensors pos (N, 3), time (N,) -> dist (N,), grad (N, 3); asynchronous."""
+        import torch
+        assert pos.is_cuda and pos.dtype == torch.float64 and pos.is_contiguous() and time.is_contiguous()
+        N = pos.shape[0]
+        dist = torch.empty(N, dtype=torch.float64, device=pos.device)
+        grad = torch.empty(N, 3, dtype=torch.float64, device=pos.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(pos.device).cuda_stream
+        self._chk(self._L.gtop_edt_query_device(self._h, N, C.c_void_p(pos.data_ptr()), C.c_void_p(time.data_ptr()),
+                                                C.c_void_p(dist.data_ptr()), C.c_void_p(grad.data_ptr()),
+                                                C.c_void_p(stream)))
+        return dist, grad
 
     # -- batched optimizer --
     @staticmethod

@@ -35,6 +35,11 @@ struct gtop_ctx {
   // ESDF construction workspace
   uint8_t *occ = nullptr;
   int *tmp1 = nullptr, *tmp2 = nullptr, *rows = nullptr;
+  double *boxes = nullptr;   // moving boxes: p0 | vel | scale, nbox x 3 each
+  size_t cap_boxes = 0;
+  int nbox = 0;
+  double *d_q = nullptr;     // host-API staging of gtop_edt_query: pos | time | dist | grad
+  size_t cap_q = 0;
   double *d_pts = nullptr;
   size_t cap_occ = 0, cap_tmp1 = 0, cap_tmp2 = 0, cap_rows = 0, pts_cap = 0;
 
@@ -247,7 +252,7 @@ int gtop_destroy(gtop_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   release_sdf(c);
-  void *bufs[] = {c->occ, c->tmp1, c->tmp2, c->rows, c->d_pts,
+  void *bufs[] = {c->occ, c->tmp1, c->tmp2, c->rows, c->boxes, c->d_q, c->d_pts,
                   c->d_T, c->d_Df, c->d_x, c->d_cost, c->d_grad,
                   c->mma_vec, c->mma_scal, c->mma_int, c->mma_f, c->mma_g, c->mma_lb, c->mma_ub};
   for (void *p : bufs)
@@ -550,6 +555,57 @@ int gtop_trajectory_stats(gtop_ctx *c, int B, const double *x, double dt_sample,
     HIPCHK(c, hipMemcpyAsync(stats, c->mma_f, (size_t)B * GTOP_TRAJ_STATS * sizeof(double), hipMemcpyDeviceToHost,
                              c->stream));
   }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
+int gtop_set_moving_boxes(gtop_ctx *c, int nbox, const double *p0, const double *vel, const double *scale) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (nbox < 0 || (nbox > 0 && (!p0 || !vel || !scale))) return fail(c, GTOP_ERR_INVALID, "set_moving_boxes: bad box list");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->nbox = 0;
+  if (nbox == 0) return GTOP_OK;
+  int rc;
+  const size_t n3 = (size_t)nbox * 3;
+  if ((rc = ensure(c, &c->boxes, &c->cap_boxes, 3 * n3))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->boxes, p0, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->boxes + n3, vel, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->boxes + 2 * n3, scale, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the host arrays may go away
+  c->nbox = nbox;
+  return GTOP_OK;
+}
+
+int gtop_edt_query_device(gtop_ctx *c, int N, const void *d_pos, const void *d_time, void *d_dist, void *d_grad,
+                          void *hip_stream) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!c->have_grid || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+  if (N < 0) return fail(c, GTOP_ERR_INVALID, "edt_query: N < 0");
+  if (N == 0) return GTOP_OK;
+  if (!d_pos || !d_time || !d_dist || !d_grad) return fail(c, GTOP_ERR_INVALID, "edt_query: NULL buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n3 = (size_t)c->nbox * 3;
+  HIPCHK(c, gtop_launch_edt_query(c->grid, c->sdf64, c->nbox, c->boxes, c->boxes + n3, c->boxes + 2 * n3, N,
+                                  static_cast<const double *>(d_pos), static_cast<const double *>(d_time),
+                                  static_cast<double *>(d_dist), static_cast<double *>(d_grad),
+                                  static_cast<hipStream_t>(hip_stream)));
+  return GTOP_OK;
+}
+
+int gtop_edt_query(gtop_ctx *c, int N, const double *pos, const double *time, double *dist, double *grad) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (N < 0 || (N > 0 && (!pos || !time || !dist || !grad))) return fail(c, GTOP_ERR_INVALID, "edt_query: bad arguments");
+  if (N == 0) return GTOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  const size_t n = (size_t)N;
+  if ((rc = ensure(c, &c->d_q, &c->cap_q, 8 * n))) return rc;
+  double *dp = c->d_q, *dt = dp + 3 * n, *dd = dt + n, *dg = dd + n;
+  HIPCHK(c, hipMemcpyAsync(dp, pos, 3 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dt, time, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if ((rc = gtop_edt_query_device(c, N, dp, dt, dd, dg, c->stream))) return rc;
+  HIPCHK(c, hipMemcpyAsync(dist, dd, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad, dg, 3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 }

@@ -1,0 +1,137 @@
+// gtop_edt.hip — batched distance queries against the static field plus moving
+// boxes, on gfx950.
+//
+// Replaces EDTEnvironment::evaluateEDTWithGrad / distToBox / minDistToAllBox
+// (src/edt_environment.cpp:26-122 of EpicOne1/grad_traj_optimization; SURVEY §8f
+// row f4: the other consumer of the trilinear stencil): value and gradient by
+// trilinear interpolation over the 8 corner voxels, each corner's value being
+// min(static distance, distance to the nearest box at the query's time); a
+// negative time means "static only" (:91-94).  A box is {p0, vel, scale}, its
+// centre at time t the constant-velocity prediction p0 + vel t
+// (obj_predictor.h:57-66).  That file is outside the reference's build and uses
+// an SDFMap API the in-tree class lacks, so the interpolation data are the
+// in-tree ones (sdf_map.cpp:201-219: base index, diff, per-axis clamped corner
+// loads — with time < 0 the result IS getDistWithGradTrilinear), a corner's
+// position is the centre of its voxel, and a query outside the map returns -1
+// with a zero gradient (sdf_map.cpp:187).
+//
+// One lane per query; the boxes (a few dozen at most) sit in LDS and are walked
+// by every lane in step, so their reads are broadcasts.  fp64.  Gather-bound:
+// 8 corner loads + 64 B of query/result per lane.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gtop_kernels.h"
+
+namespace {
+
+constexpr int kBoxChunk = 128;   // boxes staged in LDS per pass
+
+__global__ void __launch_bounds__(256)
+edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, const double *__restrict__ box_p0,
+                 const double *__restrict__ box_vel, const double *__restrict__ box_scale, int N,
+                 const double *__restrict__ pos, const double *__restrict__ time, double *__restrict__ dist,
+                 double *__restrict__ grad) {
+  __shared__ double bx[kBoxChunk][9];   // p0, vel, scale
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < N;
+  double p[3] = {0, 0, 0}, t = -1.0;
+  if (live) {
+    p[0] = pos[3 * (size_t)i];
+    p[1] = pos[3 * (size_t)i + 1];
+    p[2] = pos[3 * (size_t)i + 2];
+    t = time[i];
+  }
+  // isInMap, sdf_map.cpp:55-69
+  bool out = false;
+  for (int k = 0; k < 3; ++k) out |= (p[k] < g.min_range[k] + 1e-4) | (p[k] > g.max_range[k] - 1e-4);
+  // base index and diff, sdf_map.cpp:201-209
+  int idx[3];
+  double diff[3];
+  for (int k = 0; k < 3; ++k) {
+    const double pm = p[k] - 0.5 * g.res;
+    idx[k] = (int)floor((pm - g.origin[k]) * g.res_inv);
+    diff[k] = (p[k] - ((idx[k] + 0.5) * g.res + g.origin[k])) * g.res_inv;
+  }
+  double values[2][2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int z = 0; z < 2; ++z) {
+        // getDistance(int,int,int): per-axis clamp, sdf_map.cpp:176-183
+        const int cx = min(max(idx[0] + x, 0), g.nx - 1), cy = min(max(idx[1] + y, 0), g.ny - 1),
+                  cz = min(max(idx[2] + z, 0), g.nz - 1);
+        values[x][y][z] = field[((size_t)cx * g.ny + cy) * g.nz + cz];
+      }
+  // min over the boxes at the 8 corner centres (edt_environment.cpp:26-73, :96-98)
+  const bool dyn = live & !out & (t >= 0.0);
+  for (int b0 = 0; b0 < nbox; b0 += kBoxChunk) {
+    const int nb = min(kBoxChunk, nbox - b0);
+    __syncthreads();
+    for (int q = threadIdx.x; q < nb * 9; q += blockDim.x) {
+      const int b = q / 9, f = q - 9 * b;
+      const double *src = f < 3 ? box_p0 : (f < 6 ? box_vel : box_scale);
+      bx[b][f] = src[3 * (size_t)(b0 + b) + (f % 3)];
+    }
+    __syncthreads();
+    if (dyn) {
+      for (int b = 0; b < nb; ++b) {
+        double bmin[3], bmax[3];
+        for (int k = 0; k < 3; ++k) {
+          const double c = bx[b][k] + bx[b][3 + k] * t;
+          bmax[k] = c + 0.5 * bx[b][6 + k];
+          bmin[k] = c - 0.5 * bx[b][6 + k];
+        }
+        // per axis and corner offset: 0 inside the slab, else the distance to its nearer face (:36-40)
+        double d1[3][2];
+        for (int k = 0; k < 3; ++k)
+          for (int o = 0; o < 2; ++o) {
+            const double pt = (idx[k] + o + 0.5) * g.res + g.origin[k];
+            d1[k][o] = (pt >= bmin[k] && pt <= bmax[k]) ? 0.0 : fmin(fabs(pt - bmin[k]), fabs(pt - bmax[k]));
+          }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+              const double d2 = sqrt(d1[0][x] * d1[0][x] + d1[1][y] * d1[1][y] + d1[2][z] * d1[2][z]);   // dist.norm()
+              values[x][y][z] = d2 < values[x][y][z] ? d2 : values[x][y][z];
+            }
+      }
+    }
+  }
+  if (!live) return;
+  // trilinear value and gradient, edt_environment.cpp:104-121 (= sdf_map.cpp:221-239)
+  const double v00 = (1 - diff[0]) * values[0][0][0] + diff[0] * values[1][0][0];
+  const double v01 = (1 - diff[0]) * values[0][0][1] + diff[0] * values[1][0][1];
+  const double v10 = (1 - diff[0]) * values[0][1][0] + diff[0] * values[1][1][0];
+  const double v11 = (1 - diff[0]) * values[0][1][1] + diff[0] * values[1][1][1];
+  const double v0 = (1 - diff[1]) * v00 + diff[1] * v10;
+  const double v1 = (1 - diff[1]) * v01 + diff[1] * v11;
+  const double d = (1 - diff[2]) * v0 + diff[2] * v1;
+  double gx = (1 - diff[2]) * (1 - diff[1]) * (values[1][0][0] - values[0][0][0]);
+  gx += (1 - diff[2]) * diff[1] * (values[1][1][0] - values[0][1][0]);
+  gx += diff[2] * (1 - diff[1]) * (values[1][0][1] - values[0][0][1]);
+  gx += diff[2] * diff[1] * (values[1][1][1] - values[0][1][1]);
+  const double gy = ((1 - diff[2]) * (v10 - v00) + diff[2] * (v11 - v01)) * g.res_inv;
+  const double gz = (v1 - v0) * g.res_inv;
+  dist[i] = out ? -1.0 : d;
+  grad[3 * (size_t)i] = out ? 0.0 : gx * g.res_inv;
+  grad[3 * (size_t)i + 1] = out ? 0.0 : gy;
+  grad[3 * (size_t)i + 2] = out ? 0.0 : gz;
+}
+
+}  // namespace
+
+hipError_t gtop_launch_edt_query(const GtopGrid &g, const double *field, int nbox, const double *box_p0,
+                                 const double *box_vel, const double *box_scale, int N, const double *pos,
+                                 const double *time, double *dist, double *grad, hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(edt_query_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, g, field, nbox, box_p0, box_vel,
+                     box_scale, N, pos, time, dist, grad);
+  return hipGetLastError();
+}

@@ -87,4 +87,9 @@ hipError_t gtop_launch_coefficients(int B, int m, const double *x, const double 
 hipError_t gtop_launch_eval_trajectories(int B, int m, const double *coeff, const double *T, int t_stride,
                                          double dt_sample, double *out, hipStream_t stream);
 
+// ---- static field + moving boxes (gtop_edt.hip) -----------------------------
+hipError_t gtop_launch_edt_query(const GtopGrid &g, const double *field, int nbox, const double *box_p0,
+                                 const double *box_vel, const double *box_scale, int N, const double *pos,
+                                 const double *time, double *dist, double *grad, hipStream_t stream);
+
 #endif  // GTOP_KERNELS_H_

@@ -211,6 +211,23 @@ int gtop_eval_trajectories_device(gtop_ctx *ctx, int B, int m, const void *d_coe
 int gtop_trajectory_stats(gtop_ctx *ctx, int B, const double *x, double dt_sample,
                           double *coeff, double *stats);
 
+/* Distance queries against the static field plus moving obstacles:
+ * EDTEnvironment::evaluateEDTWithGrad / distToBox / minDistToAllBox
+ * (src/edt_environment.cpp:26-122).  Boxes are {p0, vel, scale} (nbox x 3 each,
+ * host arrays, copied): centre p0 + vel*t (obj_predictor.h:57-66), extent
+ * +-scale/2.  A query is (pos[3], time): trilinear value and gradient over
+ * the 8 corner voxels with corner value min(static, nearest box at `time`);
+ * time < 0 = static only, and then equal to getDistWithGradTrilinear
+ * (src/sdf_map.cpp:185-242).  Outside the map: dist = -1, grad = 0.  fp64,
+ * needs the fp64 field.  pos is N x 3, grad is N x 3. */
+int gtop_set_moving_boxes(gtop_ctx *ctx, int nbox, const double *p0,
+                          const double *vel, const double *scale);
+int gtop_edt_query_device(gtop_ctx *ctx, int N, const void *d_pos,
+                          const void *d_time, void *d_dist, void *d_grad,
+                          void *hip_stream);
+int gtop_edt_query(gtop_ctx *ctx, int N, const double *pos, const double *time,
+                   double *dist, double *grad);
+
 /* ---- bookkeeping the reference keeps inside the callback ------------ */
 
 /* iter_num and total_time (src/grad_traj_optimizer.cpp:284, :436); reset as

@@ -27,6 +27,14 @@ int main(void) {
     oracle_set_occupancy(&S, occ, p, 1);   /* some of them out of the map on purpose */
   }
   oracle_esdf_build(&S, occ, dist);
+  {   /* static field + moving boxes, in and out of the map, t < 0 and t >= 0 */
+    double p0[6] = {origin[0] + 1.0, origin[1] + 1.0, 1.0, origin[0] + 3.0, origin[1] + 2.0, 2.0};
+    double vel[6] = {0.3, -0.2, 0.0, -0.5, 0.1, 0.1}, scale[6] = {0.5, 0.7, 0.9, 1.1, 0.4, 0.6}, g3[3];
+    for (int k = 0; k < 300; ++k) {
+      double p[3] = {origin[0] + urand(&seed) * 5.5 - 0.3, origin[1] + urand(&seed) * 4.6 - 0.3, urand(&seed) * 3.6 - 0.2};
+      (void)oracle_edt_query(&S, 2, p0, vel, scale, p, urand(&seed) * 4.0 - 1.0, g3);
+    }
+  }
 
   int rc = 0;
   for (int m = 2; m <= 7; ++m) {

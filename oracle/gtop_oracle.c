@@ -367,6 +367,83 @@ double oracle_sdf_query(const oracle_sdf *S, const double pos[3],
   return dist;
 }
 
+/* EDTEnvironment::distToBox / minDistToAllBox, src/edt_environment.cpp:26-73.
+ * A box is {p0, vel, scale}: its centre at `time` is the constant-velocity
+ * prediction p0 + vel*time (ObjPrediction::evaluateConstVel,
+ * include/grad_traj_optimization/obj_predictor.h:57-66). */
+static double edt_min_dist_to_boxes(int nbox, const double *p0, const double *vel, const double *scale,
+                                    const double pt[3], double time) {
+  double dist = 10000000.0; /* :64 */
+  for (int b = 0; b < nbox; ++b) {
+    double d2 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      double c = p0[3 * b + i] + vel[3 * b + i] * time;
+      double bmax = c + 0.5 * scale[3 * b + i], bmin = c - 0.5 * scale[3 * b + i]; /* :31-32 */
+      double di = (pt[i] >= bmin && pt[i] <= bmax) ? 0.0 : fmin(fabs(pt[i] - bmin), fabs(pt[i] - bmax)); /* :36-40 */
+      d2 += di * di;
+    }
+    double di = sqrt(d2); /* dist.norm(), :42 */
+    if (di < dist) dist = di;
+  }
+  return dist;
+}
+
+/* EDTEnvironment::evaluateEDTWithGrad, src/edt_environment.cpp:75-122: the
+ * trilinear value/gradient over corner values min(static distance, distance
+ * to the nearest moving box at `time`); time < 0 means static only (:91-94).
+ * That file is not part of the reference's build and calls an SDFMap API the
+ * in-tree class does not have (getInterpolationData); the interpolation data
+ * here are the in-tree ones (sdf_map.cpp:201-219: base index, diff, per-axis
+ * clamped corner loads), a corner's position is the centre of its (unclamped)
+ * voxel, and a query outside the map returns -1 with a zero gradient as
+ * oracle_sdf_query does.  PARITY UNPINNED (no reference output exists). */
+double oracle_edt_query(const oracle_sdf *S, int nbox, const double *box_p0, const double *box_vel,
+                        const double *box_scale, const double pos[3], double time, double grad[3]) {
+  if (!sdf_in_map(S, pos)) {
+    grad[0] = grad[1] = grad[2] = 0.0;
+    return -1;
+  }
+  double res = S->resolution, rinv = S->resolution_inv;
+  double pos_m[3], idx_pos[3], diff[3];
+  int idx[3];
+  for (int i = 0; i < 3; ++i) pos_m[i] = pos[i] - 0.5 * res * 1.0;
+  sdf_pos_to_index(S, pos_m, idx);
+  for (int i = 0; i < 3; ++i) idx_pos[i] = (idx[i] + 0.5) * res + S->origin[i];
+  for (int i = 0; i < 3; ++i) diff[i] = (pos[i] - idx_pos[i]) * rinv;
+
+  double values[2][2][2];
+  for (int x = 0; x < 2; x++)
+    for (int y = 0; y < 2; y++)
+      for (int z = 0; z < 2; z++) {
+        double d1 = sdf_get_distance(S, idx[0] + x, idx[1] + y, idx[2] + z);
+        if (time < 0.0) { /* :91-94 */
+          values[x][y][z] = d1;
+        } else {
+          double pt[3] = {(idx[0] + x + 0.5) * res + S->origin[0], (idx[1] + y + 0.5) * res + S->origin[1],
+                          (idx[2] + z + 0.5) * res + S->origin[2]};
+          double d2 = edt_min_dist_to_boxes(nbox, box_p0, box_vel, box_scale, pt, time);
+          values[x][y][z] = d1 < d2 ? d1 : d2; /* :98 */
+        }
+      }
+
+  double v00 = (1 - diff[0]) * values[0][0][0] + diff[0] * values[1][0][0]; /* :104-112 */
+  double v01 = (1 - diff[0]) * values[0][0][1] + diff[0] * values[1][0][1];
+  double v10 = (1 - diff[0]) * values[0][1][0] + diff[0] * values[1][1][0];
+  double v11 = (1 - diff[0]) * values[0][1][1] + diff[0] * values[1][1][1];
+  double v0 = (1 - diff[1]) * v00 + diff[1] * v10;
+  double v1 = (1 - diff[1]) * v01 + diff[1] * v11;
+  double dist = (1 - diff[2]) * v0 + diff[2] * v1;
+
+  grad[2] = (v1 - v0) * rinv; /* :114-121 */
+  grad[1] = ((1 - diff[2]) * (v10 - v00) + diff[2] * (v11 - v01)) * rinv;
+  grad[0] = (1 - diff[2]) * (1 - diff[1]) * (values[1][0][0] - values[0][0][0]);
+  grad[0] += (1 - diff[2]) * diff[1] * (values[1][1][0] - values[0][1][0]);
+  grad[0] += diff[2] * (1 - diff[1]) * (values[1][0][1] - values[0][0][1]);
+  grad[0] += diff[2] * diff[1] * (values[1][1][1] - values[0][1][1]);
+  grad[0] *= rinv;
+  return dist;
+}
+
 /* sdf_map.cpp:80-99: mark the voxel containing pos occupied (if in map). */
 int oracle_set_occupancy(const oracle_sdf *S, double *occupancy,
                          const double pos[3], int occ) {

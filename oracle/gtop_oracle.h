@@ -44,6 +44,12 @@ void oracle_sdf_init_size(oracle_sdf *S, const double origin[3],
                           int grid_out[3]);
 double oracle_sdf_query(const oracle_sdf *S, const double pos[3],
                         double grad[3]);
+
+/* EDTEnvironment::evaluateEDTWithGrad (src/edt_environment.cpp:75-122): trilinear
+ * over min(static, moving boxes at `time`); time < 0: static only.  Boxes:
+ * p0/vel/scale, nbox x 3 each.  See the .c file for the conventions taken. */
+double oracle_edt_query(const oracle_sdf *S, int nbox, const double *box_p0, const double *box_vel,
+                        const double *box_scale, const double pos[3], double time, double grad[3]);
 int oracle_set_occupancy(const oracle_sdf *S, double *occupancy,
                          const double pos[3], int occ);
 void oracle_esdf_build(const oracle_sdf *S, const double *occupancy,

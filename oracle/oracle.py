@@ -68,6 +68,8 @@ def lib():
         L.oracle_sdf_init_size.restype = None
         L.oracle_sdf_query.argtypes = [C.POINTER(OracleSdf), dp, dp]
         L.oracle_sdf_query.restype = C.c_double
+        L.oracle_edt_query.argtypes = [C.POINTER(OracleSdf), C.c_int, dp, dp, dp, dp, C.c_double, dp]
+        L.oracle_edt_query.restype = C.c_double
         L.oracle_set_occupancy.argtypes = [C.POINTER(OracleSdf), dp, dp, C.c_int]
         L.oracle_set_occupancy.restype = C.c_int
         L.oracle_esdf_build.argtypes = [C.POINTER(OracleSdf), dp, dp]
@@ -169,6 +171,20 @@ class Sdf:
         pos = _f64(pos)
         g = np.zeros(3)
         d = lib().oracle_sdf_query(C.byref(self.c), _p(pos), _p(g))
+        return d, g
+
+    def edt_query(self, pos, time, p0, vel, scale):
+        """EDTEnvironment::evaluateEDTWithGrad for each (pos, time); boxes {p0, vel, scale}."""
+        pos = _f64(pos).reshape(-1, 3)
+        time = _f64(np.broadcast_to(time, (pos.shape[0],)))
+        p0, vel, scale = (_f64(a).reshape(-1, 3) for a in (p0, vel, scale))
+        d = np.empty(pos.shape[0])
+        g = np.empty((pos.shape[0], 3))
+        gi = np.zeros(3)
+        for i in range(pos.shape[0]):
+            d[i] = lib().oracle_edt_query(C.byref(self.c), p0.shape[0], _p(p0), _p(vel), _p(scale),
+                                          _p(np.ascontiguousarray(pos[i])), float(time[i]), _p(gi))
+            g[i] = gi
         return d, g
 
     def build_from_points(self, pts):

@@ -146,6 +146,40 @@ def test_sdf_query_conventions(oracle_mod):
         assert d == dn and np.array_equal(g, gn)
 
 
+def test_edt_query_with_moving_boxes_known_answers(oracle_mod):
+    """EDTEnvironment::evaluateEDTWithGrad restated (src/edt_environment.cpp:26-122): static-only
+    queries are the trilinear query; a box's distance is the norm of per-axis face distances;
+    the box centre moves with constant velocity."""
+    grid = (12, 10, 8)
+    rng = np.random.default_rng(7)
+    dist = rng.uniform(1.0, 3.0, grid)
+    org = np.array((-1.2, -1.0, 0.0))
+    sdf = oracle_mod.Sdf(org, 0.2, grid, dist)
+    none = np.zeros((0, 3))
+    pos = rng.uniform(org + 0.2, org + np.array(grid) * 0.2 - 0.2, size=(50, 3))
+    d, g = sdf.edt_query(pos, -1.0, none, none, none)
+    for i, p in enumerate(pos):
+        ds, gs = sdf.query(p)
+        assert d[i] == ds and np.array_equal(g[i], gs)
+    # a box given at t >= 0 is ignored at t < 0
+    box = ([[0.0, 0.0, 0.8]], [[0.5, 0.0, 0.0]], [[0.5, 0.5, 0.5]])
+    d2, _ = sdf.edt_query(pos, -0.5, *box)
+    assert np.array_equal(d, d2)
+    # every corner voxel centre inside the box -> value 0, gradient 0 (the box sits at x = 0.5 at t = 1)
+    dq, gq = sdf.edt_query(np.array([[0.5, 0.0, 0.8]]), 1.0, *box)
+    assert dq[0] == 0.0 and np.all(gq[0] == 0.0)
+    # a query at a voxel centre returns that corner's value: min(static >= 1, box distance).  Box faces at
+    # x in [0.25, 0.75] (t = 1), y in [-0.25, 0.25], z in [0.55, 1.05]; voxel centre (0.9, 0.1, 0.7) is 0.15 off in x only
+    dq, _ = sdf.edt_query(np.array([[0.9, 0.1, 0.7]]), 1.0, *box)
+    assert abs(dq[0] - 0.15) < 1e-9
+    # off in two axes: norm of the per-axis distances (0.15, 0.25)
+    dq, _ = sdf.edt_query(np.array([[0.9, 0.5, 0.7]]), 1.0, *box)
+    assert abs(dq[0] - np.hypot(0.15, 0.25)) < 1e-9
+    # out of the map: -1, zero gradient
+    dq, gq = sdf.edt_query(np.array([[5.0, 0.0, 0.5]]), 1.0, *box)
+    assert dq[0] == -1.0 and np.all(gq[0] == 0.0)
+
+
 def test_esdf_against_twin_and_scipy(oracle_mod):
     """Three implementations of the same exact EDT: the C restatement, the
     numpy twin of the same lower-envelope sweeps, and scipy's EDT."""
