@@ -175,3 +175,28 @@ def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m):
     ctx.set_launch_geometry(0, 0)
     for r in res[1:]:
         assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1])
+
+
+def test_two_step_schedule_batched(scene, oracle_mod, gtop):
+    """The reference's schedule (example_click.cpp:163-164: optimizeTrajectory(OPT_FIRST_STEP)
+    then OPT_SECOND_STEP): step 1 drops the smoothness weight (:412-415), step 2 restores
+    it.  Batched: set step, optimise, set step, optimise from the first result."""
+    mp, ctx, sdf = scene
+    B, m = 48, 6
+    b = problem.make_trajectories(B, m, mp, seed=555)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    ctx.set_problem(b.T, b.Df)
+    ctx.set_params(step=1)
+    x1, c1 = ctx.optimize_batch(b.x, lb, ub, 20)
+    p1 = oracle_mod.make_params(step=1)
+    c_start1, _, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, p1)
+    c_end1, _, _ = oracle_mod.eval_batch(b.T, b.Df, x1, sdf, p1)
+    assert np.allclose(c1, c_end1, rtol=1e-6) and (c_end1 <= c_start1 + 1e-12).all()
+    ctx.set_params(step=2)
+    x2, c2 = ctx.optimize_batch(x1, lb, ub, 20)
+    p2 = oracle_mod.make_params(step=2)
+    c_start2, _, _ = oracle_mod.eval_batch(b.T, b.Df, x1, sdf, p2)
+    c_end2, _, _ = oracle_mod.eval_batch(b.T, b.Df, x2, sdf, p2)
+    assert np.allclose(c2, c_end2, rtol=1e-6) and (c_end2 <= c_start2 + 1e-12).all()
+    assert (c_end2 < c_start2).mean() > 0.9
+    ctx.set_params()
