@@ -158,7 +158,10 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
 // -> spl 3 (one wavefront per trajectory: more wavefronts in flight).
 void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb, int auto_spl = 0) {
   int s = c->spl;
-  if (s == 0) s = auto_spl ? auto_spl : ((B >= 4096) ? c->auto_spl_large : c->auto_spl_small);
+  // auto rule (measured): up to 512 trajectories (1536 wavefronts on 1024 SIMDs) it pays to
+  // spread a trajectory over three wavefronts (latency: one sample per lane); then one wavefront per trajectory;
+  // from 4096 on two trajectories per wavefront
+  if (s == 0) s = auto_spl ? auto_spl : (B <= 512 ? 1 : ((B >= 4096) ? c->auto_spl_large : c->auto_spl_small));
   const int spw = gtop_eval_segments_per_wave(s);
   int w = c->waves > 0 ? c->waves : (spw >= m ? 1 : (m + spw - 1) / spw);
   if (w < 1) w = 1;

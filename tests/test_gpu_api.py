@@ -233,7 +233,8 @@ def test_full_size_batch_properties(full_scene, oracle_mod, cfg):
     c2, g2 = ctx.eval_device(x[h:].contiguous(), Df[h:].contiguous(), T[h:].contiguous())
     cr, gr = ctx.eval_device(x.flip(0).contiguous(), Df.flip(0).contiguous(), T.flip(0).contiguous())
     torch.cuda.synchronize()
-    if B // 2 >= 4096 or B < 4096:       # same auto launch geometry for the halves as for the whole
+    bracket = lambda nb: 0 if nb <= 512 else (1 if nb < 4096 else 2)   # the auto launch-geometry rule
+    if bracket(B // 2) == bracket(B):    # same geometry for the halves as for the whole: same summation order
         assert torch.equal(torch.cat([c1, c2]), c) and torch.equal(torch.cat([g1, g2]), g)
     assert torch.equal(cr.flip(0), c) and torch.equal(gr.flip(0), g)
     # subsample against the oracle

@@ -141,9 +141,11 @@ def test_optimize_device_api_and_determinism(scene, gtop):
         torch.cuda.synchronize()
         out.append((x.clone(), c.clone()))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])   # bitwise repeatable
+    ctx.set_launch_geometry(0, 3)                # the optimizer's geometry: same summation order
     c0, _ = ctx.eval_device(torch.tensor(b.x, device=dev), Df, T)
     c1, _ = ctx.eval_device(out[0][0], Df, T)
     torch.cuda.synchronize()
+    ctx.set_launch_geometry(0, 0)
     assert torch.equal(c1, out[0][1])            # min_cost is the cost of the returned x
     assert (c1 <= c0).all() and (c1 < 0.5 * c0).float().mean() > 0.9
 

@@ -16,6 +16,7 @@ ctx = gtop.GtopContext(0)
 ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
 ctx.update_sdf_map(mp.obstacle_points())
 ctx.set_params()
+ctx.set_launch_geometry(0, int(os.environ.get("SPL", "0")))
 for B in [int(a) for a in sys.argv[1:]] or [1, 1024, 16384]:
     b = problem.make_trajectories(B, 6, mp, seed=1)
     ctx.set_problem(b.T, b.Df)
