@@ -103,3 +103,18 @@ def test_parity_wide_index_field(gtop, oracle_mod):
         torch.cuda.synchronize()
         rc, rg = rel_err(c32.cpu().numpy().astype(np.float64), g32.cpu().numpy().astype(np.float64), c_ref, g_ref)
         assert rc <= 2e-3 and rg <= 2e-3, (spl, rc, rg)
+
+
+@pytest.mark.parametrize("m", [40, 90])
+def test_fp64_parity_long_trajectories(scene, oracle_mod, m):
+    """Many segments: several sample passes per wavefront, up to 8 wavefronts per workgroup and
+    (m = 90) more than 64 KB of LDS per workgroup (opt-in dynamic LDS)."""
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(5, m, mp, seed=4000 + m, step_len=(0.3, 0.8))
+    ctx.set_launch_geometry(0, 0)
+    ctx.set_params()
+    ctx.set_problem(b.T, b.Df)
+    c, g = ctx.eval_batch(b.x)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params())
+    rc, rg = rel_err(c, g, c_ref, g_ref)
+    assert rc <= TOL64 and rg <= TOL64, (rc, rg)
