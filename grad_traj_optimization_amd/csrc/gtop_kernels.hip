@@ -61,6 +61,9 @@ constexpr int red_stride(int spl) {
   const int lps = kSamples / spl, busy = lps * (64 / lps);
   return busy | 1;
 }
+#ifndef GTOP_PIN_CONSTS
+#define GTOP_PIN_CONSTS 2
+#endif
 #ifndef GTOP_PREISSUE
 #define GTOP_PREISSUE 0
 #endif
@@ -100,25 +103,39 @@ template <> __device__ __forceinline__ float gexp<float>(float v) { return expf(
 // instructions of the library routine.  |x| beyond the fp64 exponent range
 // saturates to 0 / inf through v_cvt_i32_f64 (saturating) and v_ldexp_f64;
 // NaN propagates through p.
-__device__ __forceinline__ double penalty_exp(double x) {
-  const double k = rint(x * 1.4426950408889634074);            // x / ln2
-  double r = fma(k, -6.93147180369123816490e-01, x);            // ln2 hi
-  r = fma(k, -1.90821492927058770002e-10, r);                   // ln2 lo
-  double p = 2.505210838544172e-08;                             // 1/11!
-  p = fma(p, r, 2.755731922398589e-07);                         // 1/10!
-  p = fma(p, r, 2.7557319223985893e-06);                        // 1/9!
-  p = fma(p, r, 2.48015873015873e-05);                          // 1/8!
-  p = fma(p, r, 1.984126984126984e-04);                         // 1/7!
-  p = fma(p, r, 1.388888888888889e-03);                         // 1/6!
-  p = fma(p, r, 8.333333333333333e-03);                         // 1/5!
-  p = fma(p, r, 4.1666666666666664e-02);                        // 1/4!
-  p = fma(p, r, 1.6666666666666666e-01);                        // 1/3!
+// The constants live in a struct so that the unrolled small-batch bodies can pin them
+// in VGPRs (ExpConsts::pin): 24 literal dwords less to hold in SGPRs, which those bodies
+// otherwise spill to VGPR lanes and re-materialise with s_mov pairs.
+struct ExpConsts {
+  double inv_ln2 = 1.4426950408889634074, ln2_hi = -6.93147180369123816490e-01, ln2_lo = -1.90821492927058770002e-10;
+  double c[9] = {2.505210838544172e-08,    // 1/11!
+                 2.755731922398589e-07,    // 1/10!
+                 2.7557319223985893e-06,   // 1/9!
+                 2.48015873015873e-05,     // 1/8!
+                 1.984126984126984e-04,    // 1/7!
+                 1.388888888888889e-03,    // 1/6!
+                 8.333333333333333e-03,    // 1/5!
+                 4.1666666666666664e-02,   // 1/4!
+                 1.6666666666666666e-01};  // 1/3!
+  __device__ __forceinline__ void pin() {
+    asm volatile("" : "+v"(inv_ln2), "+v"(ln2_hi), "+v"(ln2_lo));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(c[i]));
+  }
+};
+__device__ __forceinline__ double penalty_exp(double x, const ExpConsts &K) {
+  const double k = rint(x * K.inv_ln2);            // x / ln2
+  double r = fma(k, K.ln2_hi, x);
+  r = fma(k, K.ln2_lo, r);
+  double p = K.c[0];
+#pragma unroll
+  for (int i = 1; i < 9; ++i) p = fma(p, r, K.c[i]);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   return ldexp(p, (int)k);   // v_cvt_i32_f64: saturating, NaN -> 0
 }
-__device__ __forceinline__ float penalty_exp(float x) { return expf(x); }
+__device__ __forceinline__ float penalty_exp(float x, const ExpConsts &) { return expf(x); }
 
 // 1/x: hardware estimate + two Newton steps (fp64), full-precision divide (fp32)
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -225,17 +242,32 @@ template <typename R> struct SdfTap {
   bool out, zflat;              // outside the map; clamped at a z border (zero z-gradient)
 };
 
+// isInMap's box (sdf_map.cpp:55-69, margins included); a struct so that the unrolled
+// small-batch bodies can keep it in VGPRs instead of 12 SGPRs (see ExpConsts)
+template <typename R> struct MapBox {
+  R lo[3], hi[3];
+  R org[3], half, rinv;   // origin, res/2, 1/res of posToIndex (sdf_map.cpp:71-74, :201-204)
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(lo[i]), "+v"(hi[i]));
+  }
+  __device__ __forceinline__ void pin_index() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(org[i]));
+    asm volatile("" : "+v"(half), "+v"(rinv));
+  }
+};
+
 template <typename R, bool WIDE>
-__device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, R px, R py, R pz) {
+__device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, const MapBox<R> &box, R px, R py, R pz) {
   SdfTap<R> tp;
-  tp.out = (px < a.lo[0]) | (py < a.lo[1]) | (pz < a.lo[2]) |
-           (px > a.hi[0]) | (py > a.hi[1]) | (pz > a.hi[2]);
-  const R res = a.res, rinv = a.res_inv;
-  const R half = (R)0.5 * res;
+  tp.out = (px < box.lo[0]) | (py < box.lo[1]) | (pz < box.lo[2]) |
+           (px > box.hi[0]) | (py > box.hi[1]) | (pz > box.hi[2]);
+  const R rinv = box.rinv, half = box.half;
   // posToIndex(pos - 0.5 res)  (:201-204 -> :71-74)
-  const R ux = ((px - half) - a.origin[0]) * rinv;
-  const R uy = ((py - half) - a.origin[1]) * rinv;
-  const R uz = ((pz - half) - a.origin[2]) * rinv;
+  const R ux = ((px - half) - box.org[0]) * rinv;
+  const R uy = ((py - half) - box.org[1]) * rinv;
+  const R uz = ((pz - half) - box.org[2]) * rinv;
   const R fx = gfloor(ux), fy = gfloor(uy);
   const int ix = (int)fx, iy = (int)fy, iz = (int)gfloor(uz);
   // indexToPos (:76-78) and diff (:209): (pos - centre(idx)) / res is the fractional
@@ -501,6 +533,14 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   R *myred = red + wave * (kRedChunk * kRedStride);
 
   const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
+  ExpConsts expk;
+  MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
+                      {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
+  if constexpr (GTOP_PIN_CONSTS && !kIsF32<R> && SPL <= 3 && !MMA && !DYN) {   // (MMA/DYN bodies have no VGPRs to spare)
+    expk.pin();
+    if (GTOP_PIN_CONSTS > 1) mapbox.pin();
+    if (GTOP_PIN_CONSTS > 2) mapbox.pin_index();
+  }
   const R wc = a.wc;
   const bool do_colli = !(gabs(wc) < (R)1e-4);  // :346
 
@@ -665,7 +705,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
               if (DYN)  // :497-502
                 accs[c][k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
             }
-            taps[c] = sdf_issue<R, WIDE>(a, pos[0], pos[1], pos[2]);   // :363
+            taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
           }
           if constexpr (CH > 1) __builtin_amdgcn_sched_barrier(0);   // keep every load of stage A above stage B
 #ifdef GTOP_STAMPS
@@ -689,7 +729,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
           const R dist = sdf_blend(taps[c], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
           // samples past the loop bound of :353 and idle lanes contribute nothing:
           // every term below carries a factor e
-          const R e = live ? penalty_exp((a.d0 - dist) * a.inv_r) : (R)0;   // exp(-(d - d0)/r)
+          const R e = live ? penalty_exp((a.d0 - dist) * a.inv_r, expk) : (R)0;   // exp(-(d - d0)/r)
           const R cd = a.alpha * e;                    // :509
           const R gd = -a.alpha_over_r * e;            // :514
           R csum = wdt * (cd * vn);                    // :373, weighted as in :417-418
