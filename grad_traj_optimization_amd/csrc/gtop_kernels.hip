@@ -534,12 +534,14 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
 
   const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
   ExpConsts expk;
+  R pen_d0 = a.d0, pen_inv_r = a.inv_r, pen_alpha = a.alpha, pen_gd = -a.alpha_over_r;   // penalty parameters (:507-515)
   MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
                       {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
   if constexpr (GTOP_PIN_CONSTS && !kIsF32<R> && SPL <= 3 && !MMA && !DYN) {   // (MMA/DYN bodies have no VGPRs to spare)
     expk.pin();
     if (GTOP_PIN_CONSTS > 1) mapbox.pin();
     if (GTOP_PIN_CONSTS > 2) mapbox.pin_index();
+    if (GTOP_PIN_CONSTS > 3) asm volatile("" : "+v"(pen_d0), "+v"(pen_inv_r), "+v"(pen_alpha), "+v"(pen_gd));
   }
   const R wc = a.wc;
   const bool do_colli = !(gabs(wc) < (R)1e-4);  // :346
@@ -729,9 +731,9 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
           const R dist = sdf_blend(taps[c], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
           // samples past the loop bound of :353 and idle lanes contribute nothing:
           // every term below carries a factor e
-          const R e = live ? penalty_exp((a.d0 - dist) * a.inv_r, expk) : (R)0;   // exp(-(d - d0)/r)
-          const R cd = a.alpha * e;                    // :509
-          const R gd = -a.alpha_over_r * e;            // :514
+          const R e = live ? penalty_exp((pen_d0 - dist) * pen_inv_r, expk) : (R)0;   // exp(-(d - d0)/r)
+          const R cd = pen_alpha * e;                  // :509
+          const R gd = pen_gd * e;                     // :514
           R csum = wdt * (cd * vn);                    // :373, weighted as in :417-418
           // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
           const R f1 = is_out ? (R)0 : (wdt * a.res_inv) * (gd * cd * vn), f2 = wdt * (cd * ivn);   // 1/res: g3's unit
