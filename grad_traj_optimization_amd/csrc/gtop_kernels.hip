@@ -13,16 +13,21 @@
 // (src/qp_generator.cpp:357-405).  A is block diagonal, so L's row-block s is
 // A_s^-1 (quintic Hermite, closed form) scattered onto the columns of
 // waypoints s and s+1, and d'Rd = sum_s c_s' Q_s c_s.  The kernel therefore
-// takes (x, Df, T) and works per segment:
-//   phase 1  c_{s,k} = A_s^-1 d_{s,k};  jerk cost and 2 Q_s c (coefficient space)
-//   phase 2  30 samples per segment, one lane per sample (32-lane half-wave
-//            per segment): position/velocity, trilinear SDF gather, exp
-//            penalty; each sample contributes w1_k*[t^j] + w2_k*[j t^(j-1)]
-//            to an 18-entry coefficient-space gradient, reduced through LDS
-//   phase 3  A_s^-T maps the 6 coefficient-space entries of (s,k) to the
-//            derivative space [p0,pT,v0,vT,a0,aT]
-//   phase 4  each free variable sums its two adjacent segments, +1e-5; the
-//            scalar cost is a wavefront shuffle reduction.
+// takes (x, Df, T) and works per segment (geometry: DESIGN.md §5.1 — a segment
+// is sampled by LPS = 30/SPL adjacent lanes with SPL samples each, a wavefront
+// holds 64/LPS segments of one or more trajectories):
+//   phase 1  one lane per (segment, axis): c_{s,k} = A_s^-1 d_{s,k}, the jerk cost
+//            c'Qc and the jerk gradient 2Qc taken to derivative space by A_s^-T
+//   phase 2  per sample: position/velocity (float round trip), trilinear field
+//            lookup with analytic gradient, exp penalty; each sample adds
+//            w1_k*[t^j] + w2_k*[j t^(j-1)] to the lane's 18-entry
+//            coefficient-space gradient; after its samples the lane applies
+//            A_s^-T (linear, commutes with the sums) and the LPS lanes of a
+//            segment are summed through a per-wavefront LDS tile
+//   phase 4  each free variable = end of segment w-1 + start of segment w,
+//            +1e-5; the scalar cost is a DPP wavefront reduction, +1e-3; with
+//            MMA = true the workgroup then runs the optimizer update and
+//            evaluates again (the whole CCSA-MMA loop in one launch).
 // All structural zeros the reference multiplies through are skipped; nothing
 // else is approximated.
 
@@ -828,7 +833,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
           }
         } else {
           // transpose-reduce over the LPS lanes of each segment through LDS, kRedChunk
-          // of the 19 values at a time (tile = kRedChunk x 65 elements)
+          // of the 19 values at a time (tile = kRedChunk rows of kRedStride elements)
 #pragma unroll
           for (int c0 = 0; c0 < kRedVals; c0 += kRedChunk) {
             const int cn = (kRedVals - c0) < kRedChunk ? (kRedVals - c0) : kRedChunk;
