@@ -506,7 +506,7 @@ template <int SPL, bool DYN, bool MMA> struct MinWaves<float, SPL, DYN, MMA> { s
 // point st.xcur of the batched CCSA-MMA driver, and after cost and gradient of
 // a trajectory are known the same workgroup runs its MMA update
 // (gtop_mma_update_trajectory) and — st.iters times in all — evaluates again.
-template <typename R, bool DYN, int SPL, bool MMA, bool WIDE>
+template <typename R, bool DYN, int SPL, bool MMA, bool WIDE, bool ONE>
 __global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R, SPL, DYN, MMA>::v)) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
@@ -520,9 +520,14 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *sm = reinterpret_cast<R *>(smem_raw);
   const int m = a.m, ndp = 3 * m - 3, n = 3 * ndp;
-  const int TPB = a.tpb, MS = TPB * m;       // trajectories / virtual segments per workgroup
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, NW = nthr >> 6;
+  // ONE: the launcher guarantees one wavefront per workgroup holding one whole trajectory
+  // (2 <= m <= SPW).  With that known at compile time the work-distribution loops of every
+  // phase collapse to straight-line code — a lone wavefront pays four cycles per instruction.
+  if constexpr (ONE) __builtin_assume(m >= 2 && m <= SPW);
+  const int TPB = ONE ? 1 : a.tpb, MS = TPB * m;   // trajectories / virtual segments per workgroup
+  const int tid = threadIdx.x, nthr = ONE ? 64 : (int)blockDim.x;
+  if constexpr (ONE) __builtin_assume(tid >= 0 && tid < 64);
+  const int lane = tid & 63, wave = ONE ? 0 : tid >> 6, NW = ONE ? 1 : nthr >> 6;
   const int slot = lane / LPS, li = lane - slot * LPS;   // segment slot in this wave, lane in segment
 
   R *Ts = sm;                // [MS]       segment_time
@@ -569,7 +574,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
     const int npass = MMA ? st.iters : 1;
     for (int pass = 0; pass < npass; ++pass) {
     GTOP_STAMP(0);
-    const int ntraj = min(TPB, a.B - b0);   // trajectories this pass
+    const int ntraj = ONE ? 1 : min(TPB, a.B - b0);   // trajectories this pass
     const int nseg = ntraj * m;             // live virtual segments
     // ---- phase 1: per (segment, axis): coefficients, jerk cost and jerk gradient ----
     // Its 3*m*TPB lanes read their seven inputs (two waypoints' p,v,a and T_s)
@@ -577,7 +582,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
     for (int w = tid; w < 3 * nseg; w += nthr) {
       const int S = w / 3, k = w - 3 * S;
       int tl = 0, s = S;
-      while (s >= m) { s -= m; ++tl; }
+      if constexpr (!ONE) while (s >= m) { s -= m; ++tl; }
       const R *xk = a.x + (size_t)(b0 + tl) * n + k * ndp;    // free variables of axis k (:182-187)
       const R *df = a.Df + (size_t)(b0 + tl) * 18 + k * 6;    // [p,v,a]_start, [p,v,a]_end
       // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
@@ -619,6 +624,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
         dts[S] = T / (R)30.0;   // :351
         if (!do_colli) ccol[S] = (R)0;   // (aliases Ts: only when the sample phase will not read it)
       }
+      if constexpr (ONE) break;   // 3 m <= 18 work items: one trip
     }
     __syncthreads();
     GTOP_STAMP(1);
@@ -879,6 +885,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
             __builtin_amdgcn_wave_barrier();
           }
         }
+        if constexpr (ONE) break;   // m <= SPW segments: one pass
       }
     } else {
       for (int q = tid; q < 18 * nseg; q += nthr) gseg[q] = Gs[q];   // |wc| < 1e-4: no collision term (:346)
@@ -895,7 +902,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
       R *fc = dts;   // [TPB]    cost copy (dts is dead after phase 2)
       for (int q = tid; q < ntraj * n; q += nthr) {
         int tl = 0, i = q;
-        while (i >= n) { i -= n; ++tl; }
+        if constexpr (!ONE) while (i >= n) { i -= n; ++tl; }
         const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
         const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
         const R *gs = gseg + tl * m * 18;
@@ -903,14 +910,20 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
                     gs[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
         if (MMA) gl[q] = v + (R)1e-5;   // consumed by the update below; nothing leaves the chip
         else gb[q] = v + (R)1e-5;
+        if constexpr (ONE) break;   // n <= 45 free variables: one trip
       }
 #ifdef GTOP_STAMPS
       GTOP_STAMP(13);
 #endif
       for (int tl = wave; tl < ntraj; tl += NW) {   // one wavefront reduction per trajectory
         R part = (R)0;
-        for (int i = lane; i < 3 * m; i += 64) part += ws * csm[tl * 3 * m + i];
-        for (int i = lane; i < m; i += 64) part += ccol[tl * m + i];
+        if constexpr (ONE) {
+          if (lane < 3 * m) part = ws * csm[lane];
+          if (lane < m) part += ccol[lane];
+        } else {
+          for (int i = lane; i < 3 * m; i += 64) part += ws * csm[tl * 3 * m + i];
+          for (int i = lane; i < m; i += 64) part += ccol[tl * m + i];
+        }
         part = wave_sum(part);
         if (lane == 0) {
           if (MMA) fc[tl] = part + (R)1e-3;
@@ -924,8 +937,10 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
       }
     }
     GTOP_STAMP(6);
+    if constexpr (ONE && !MMA) break;   // nothing follows: no group, no pass
     __syncthreads();   // LDS is reused by the next pass / the next group of this block
     }
+    if constexpr (ONE) break;   // the launcher gives every group its own workgroup
   }
 }
 
@@ -949,23 +964,27 @@ template <typename R, bool DYN, bool MMA, bool WIDE>
 static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, int grid,
                              size_t smem, hipStream_t stream) {
   void (*kern)(const GtopKernelArgs<R>, const GtopMmaState) = nullptr;
-  if constexpr (MMA) {   // the fused optimizer step is built for the two geometries the auto rule picks
+  // the specialised body for one wavefront = one whole trajectory (the small-batch geometry)
+  const int groups = (args.B + args.tpb - 1) / args.tpb;
+  const bool one = spl == 3 && waves == 1 && args.tpb == 1 && args.m >= 2 && args.m <= gtop_eval_segments_per_wave(3) &&
+                   grid == 8 * ((groups + 7) / 8);   // (no grid-stride loop in that body)
+  if constexpr (MMA) {   // the fused optimizer step is built for the geometries the auto rules pick
     switch (spl) {
-      case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE>; break;
-      case 3: kern = gtop_eval_kernel<R, DYN, 3, true, WIDE>; break;
-      case 6: kern = gtop_eval_kernel<R, DYN, 6, true, WIDE>; break;
+      case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE, false>; break;
+      case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, true, WIDE, true> : gtop_eval_kernel<R, DYN, 3, true, WIDE, false>; break;
+      case 6: kern = gtop_eval_kernel<R, DYN, 6, true, WIDE, false>; break;
       default: return hipErrorInvalidValue;
     }
   } else {
     switch (spl) {
-      case 1: kern = gtop_eval_kernel<R, DYN, 1, false, WIDE>; break;
-      case 2: kern = gtop_eval_kernel<R, DYN, 2, false, WIDE>; break;
-      case 3: kern = gtop_eval_kernel<R, DYN, 3, false, WIDE>; break;
-      case 5: kern = gtop_eval_kernel<R, DYN, 5, false, WIDE>; break;
-      case 6: kern = gtop_eval_kernel<R, DYN, 6, false, WIDE>; break;
-      case 10: kern = gtop_eval_kernel<R, DYN, 10, false, WIDE>; break;
-      case 15: kern = gtop_eval_kernel<R, DYN, 15, false, WIDE>; break;
-      case 30: kern = gtop_eval_kernel<R, DYN, 30, false, WIDE>; break;
+      case 1: kern = gtop_eval_kernel<R, DYN, 1, false, WIDE, false>; break;
+      case 2: kern = gtop_eval_kernel<R, DYN, 2, false, WIDE, false>; break;
+      case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, false, WIDE, true> : gtop_eval_kernel<R, DYN, 3, false, WIDE, false>; break;
+      case 5: kern = gtop_eval_kernel<R, DYN, 5, false, WIDE, false>; break;
+      case 6: kern = gtop_eval_kernel<R, DYN, 6, false, WIDE, false>; break;
+      case 10: kern = gtop_eval_kernel<R, DYN, 10, false, WIDE, false>; break;
+      case 15: kern = gtop_eval_kernel<R, DYN, 15, false, WIDE, false>; break;
+      case 30: kern = gtop_eval_kernel<R, DYN, 30, false, WIDE, false>; break;
       default: return hipErrorInvalidValue;
     }
   }
