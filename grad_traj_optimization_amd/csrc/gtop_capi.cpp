@@ -62,8 +62,8 @@ struct gtop_ctx {
   int spl = 0;     // samples per lane, 0 = auto
   int fuse_mma = 2;         // optimizer: 0 separate update launch, 1 update fused into the evaluation kernel,
                             //            2 (default) the whole loop in one launch (tuning/debug knob)
-  int auto_spl_small = 3;   // what auto picks for B < 4096 (m = 6: one wavefront per trajectory)
-  int auto_spl_large = 6;   // what auto picks for B >= 4096 (m = 6: two trajectories per wavefront)
+  int auto_spl_small = 3;   // auto, mid-size batches (m = 6: one wavefront per trajectory)
+  int auto_spl_large = 6;   // auto, large batches (m = 6: two trajectories per wavefront)
 
   // bookkeeping of the callback (grad_traj_optimizer.cpp:284, :436, :439-447)
   int64_t iter_num = 0;
@@ -152,16 +152,19 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
 // Launch geometry.  spl (samples per lane, a divisor of 30) sets how many
 // segments one wavefront holds (spw = 2, 4, 6, 10, 12, 21, 32, 64 for spl =
 // 1, 2, 3, 5, 6, 10, 15, 30); a workgroup of `waves` wavefronts then owns
-// tpb = floor(waves*spw / m) whole trajectories (at least 1).  Auto (measured,
-// profiles/r1/sweep_geometry_v4.txt): B >= 4096 -> spl 6 (two 20-control-point
-// trajectories per wavefront, amortising the few-lane phases); smaller batches
-// -> spl 3 (one wavefront per trajectory: more wavefronts in flight).
-void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb, int auto_spl = 0) {
+// tpb = floor(waves*spw / m) whole trajectories (at least 1).
+void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb, int auto_spl = 0,
+                     bool f32 = false) {
   int s = c->spl;
-  // auto rule (measured): up to 512 trajectories (1536 wavefronts on 1024 SIMDs) it pays to
-  // spread a trajectory over three wavefronts (latency: one sample per lane); then one wavefront per trajectory;
-  // from 4096 on two trajectories per wavefront
-  if (s == 0) s = auto_spl ? auto_spl : (B <= 512 ? 1 : ((B >= 4096) ? c->auto_spl_large : c->auto_spl_small));
+  // auto rule (measured): up to 256 trajectories a trajectory is spread over three wavefronts
+  // (latency: one sample per lane); then one wavefront per trajectory, which for m <= 6 is the specialised
+  // straight-line body; the two-trajectories-per-wavefront body takes over once the GPU is several rounds deep
+  if (s == 0) {
+    if (auto_spl) s = auto_spl;
+    else if (B <= 256) s = 1;
+    else if (m <= 6) s = (B >= (f32 ? 12288 : 16384)) ? c->auto_spl_large : c->auto_spl_small;
+    else s = (B >= 4096) ? c->auto_spl_large : c->auto_spl_small;
+  }
   const int spw = gtop_eval_segments_per_wave(s);
   int w = c->waves > 0 ? c->waves : (spw >= m ? 1 : (m + spw - 1) / spw);
   if (w < 1) w = 1;
@@ -207,7 +210,7 @@ int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const 
   a.grad = static_cast<R *>(d_grad);
   a.B = B; a.m = m; a.t_stride = t_stride;
   int waves, spl, tpb;
-  launch_geometry(c, B, m, &waves, &spl, &tpb);
+  launch_geometry(c, B, m, &waves, &spl, &tpb, 0, sizeof(R) == 4);
   while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(R)) > 64 * 1024) --tpb;
   a.tpb = tpb;
   if (gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(R)) > 160 * 1024)

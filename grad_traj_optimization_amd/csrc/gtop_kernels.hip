@@ -910,7 +910,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
                     gs[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
         if (MMA) gl[q] = v + (R)1e-5;   // consumed by the update below; nothing leaves the chip
         else gb[q] = v + (R)1e-5;
-        if constexpr (ONE) break;   // n <= 45 free variables: one trip
+        if constexpr (ONE && 9 * (SPW - 1) <= 64) break;   // n = 9(m-1) <= 64 free variables: one trip
       }
 #ifdef GTOP_STAMPS
       GTOP_STAMP(13);
@@ -966,13 +966,14 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
   void (*kern)(const GtopKernelArgs<R>, const GtopMmaState) = nullptr;
   // the specialised body for one wavefront = one whole trajectory (the small-batch geometry)
   const int groups = (args.B + args.tpb - 1) / args.tpb;
-  const bool one = spl == 3 && waves == 1 && args.tpb == 1 && args.m >= 2 && args.m <= gtop_eval_segments_per_wave(3) &&
+  const bool one = (spl == 3 || spl == 6) && waves == 1 && args.tpb == 1 && args.m >= 2 &&
+                   args.m <= gtop_eval_segments_per_wave(spl) &&
                    grid == 8 * ((groups + 7) / 8);   // (no grid-stride loop in that body)
   if constexpr (MMA) {   // the fused optimizer step is built for the geometries the auto rules pick
     switch (spl) {
       case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE, false>; break;
       case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, true, WIDE, true> : gtop_eval_kernel<R, DYN, 3, true, WIDE, false>; break;
-      case 6: kern = gtop_eval_kernel<R, DYN, 6, true, WIDE, false>; break;
+      case 6: kern = one ? gtop_eval_kernel<R, DYN, 6, true, WIDE, true> : gtop_eval_kernel<R, DYN, 6, true, WIDE, false>; break;
       default: return hipErrorInvalidValue;
     }
   } else {
@@ -981,7 +982,7 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
       case 2: kern = gtop_eval_kernel<R, DYN, 2, false, WIDE, false>; break;
       case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, false, WIDE, true> : gtop_eval_kernel<R, DYN, 3, false, WIDE, false>; break;
       case 5: kern = gtop_eval_kernel<R, DYN, 5, false, WIDE, false>; break;
-      case 6: kern = gtop_eval_kernel<R, DYN, 6, false, WIDE, false>; break;
+      case 6: kern = one ? gtop_eval_kernel<R, DYN, 6, false, WIDE, true> : gtop_eval_kernel<R, DYN, 6, false, WIDE, false>; break;
       case 10: kern = gtop_eval_kernel<R, DYN, 10, false, WIDE, false>; break;
       case 15: kern = gtop_eval_kernel<R, DYN, 15, false, WIDE, false>; break;
       case 30: kern = gtop_eval_kernel<R, DYN, 30, false, WIDE, false>; break;
