@@ -40,7 +40,8 @@ struct GtopMmaState {
   int *k, *state;                                         // [B]
   int iters;                                              // evaluations per launch of the fused kernel
 };
-size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem);
+// red_rows: rows of the reduction tile (0 = the full 19; the launcher passes what the kernel variant uses)
+size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem, int red_rows = 0);
 
 // spl = samples per lane (a divisor of 30); a wavefront then holds
 // gtop_eval_segments_per_wave(spl) segments.

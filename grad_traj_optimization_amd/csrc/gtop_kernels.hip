@@ -75,7 +75,10 @@ constexpr int red_stride(int spl) {
 #ifndef GTOP_RED_CHUNK
 #define GTOP_RED_CHUNK 19
 #endif
-constexpr int kRedChunk = GTOP_RED_CHUNK;   // values per transpose-reduction pass
+constexpr int kRedChunkFull = GTOP_RED_CHUNK;   // values per transpose-reduction pass
+// The fp64 two-trajectories-per-wavefront body fits 128 VGPRs; reducing in two passes of 10 rows
+// brings its LDS to 8.8 KB per workgroup, and 16 workgroups (4 wavefronts per SIMD) fit a CU.
+constexpr int red_chunk(size_t elem, int tpbc) { return (elem == 8 && tpbc == 2) ? 10 : kRedChunkFull; }
 
 // Diagnostic build (-DGTOP_STAMPS): s_memtime at the phase boundaries of lane 0
 // of wave 0 of the first 4096 workgroups, into a buffer of its own that nothing
@@ -496,22 +499,26 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
 // waves per SIMD without spilling; the unrolled small-batch bodies need ~210 and
 // the optional velocity/acceleration block (DYN) and the optimizer epilogue (MMA) more.  fp32: 3 waves; the
 // 128-VGPR budget of 4 waves spills.
-template <typename R, int SPL, bool DYN, bool MMA> struct MinWaves {
-  static constexpr int v = (!DYN && !MMA && (SPL == 5 || SPL == 6)) ? GTOP_F64_MIN_WAVES_ROLLED : GTOP_F64_MIN_WAVES;
+template <typename R, int SPL, bool DYN, bool MMA, int TPBC> struct MinWaves {
+  static constexpr int v = (!DYN && !MMA && SPL == 6 && TPBC == 2) ? 4
+                           : (!DYN && !MMA && (SPL == 5 || SPL == 6)) ? GTOP_F64_MIN_WAVES_ROLLED : GTOP_F64_MIN_WAVES;
 };
-template <int SPL, bool DYN, bool MMA> struct MinWaves<float, SPL, DYN, MMA> { static constexpr int v = DYN ? 2 : GTOP_F32_MIN_WAVES; };
+template <int SPL, bool DYN, bool MMA, int TPBC> struct MinWaves<float, SPL, DYN, MMA, TPBC> {
+  static constexpr int v = DYN ? 2 : ((SPL == 6 && TPBC > 0 && !MMA) ? 4 : GTOP_F32_MIN_WAVES);
+};
 
 //
 // MMA = true (fp64 only) appends the optimizer step: `a.x` is then the trial
 // point st.xcur of the batched CCSA-MMA driver, and after cost and gradient of
 // a trajectory are known the same workgroup runs its MMA update
 // (gtop_mma_update_trajectory) and — st.iters times in all — evaluates again.
-template <typename R, bool DYN, int SPL, bool MMA, bool WIDE, bool ONE>
-__global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R, SPL, DYN, MMA>::v)) GTOP_WAVES_PER_EU_ATTR
+template <typename R, bool DYN, int SPL, bool MMA, bool WIDE, int TPBC>
+__global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R, SPL, DYN, MMA, TPBC>::v)) GTOP_WAVES_PER_EU_ATTR
 gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront
   constexpr int kRedStride = red_stride(SPL);
+  constexpr int kRedChunk = red_chunk(sizeof(R), TPBC);
   // up to three samples per lane are unrolled outright (the small-batch geometry: one wavefront per SIMD,
   // the scheduler interleaves the samples); longer loops stay rolled to hold 2 waves per SIMD
   constexpr int kUnroll = (SPL <= 3 && !DYN) ? SPL : GTOP_SAMPLE_UNROLL;
@@ -520,14 +527,17 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *sm = reinterpret_cast<R *>(smem_raw);
   const int m = a.m, ndp = 3 * m - 3, n = 3 * ndp;
-  // ONE: the launcher guarantees one wavefront per workgroup holding one whole trajectory
-  // (2 <= m <= SPW).  With that known at compile time the work-distribution loops of every
-  // phase collapse to straight-line code — a lone wavefront pays four cycles per instruction.
-  if constexpr (ONE) __builtin_assume(m >= 2 && m <= SPW);
-  const int TPB = ONE ? 1 : a.tpb, MS = TPB * m;   // trajectories / virtual segments per workgroup
-  const int tid = threadIdx.x, nthr = ONE ? 64 : (int)blockDim.x;
-  if constexpr (ONE) __builtin_assume(tid >= 0 && tid < 64);
-  const int lane = tid & 63, wave = ONE ? 0 : tid >> 6, NW = ONE ? 1 : nthr >> 6;
+  // TPBC > 0: the launcher guarantees one wavefront per workgroup holding TPBC whole
+  // trajectories (2 <= m, TPBC m <= SPW) and a workgroup per group.  With that known at
+  // compile time the work-distribution loops of every phase collapse to straight-line code
+  // (a lone wavefront pays four cycles per instruction of any kind) and the loop-invariant
+  // lane predicates no longer overflow the SGPR file.  ONE = the single-trajectory case.
+  constexpr bool FIXED = TPBC > 0, ONE = TPBC == 1;
+  if constexpr (FIXED) __builtin_assume(m >= 2 && TPBC * m <= SPW);
+  const int TPB = FIXED ? TPBC : a.tpb, MS = TPB * m;   // trajectories / virtual segments per workgroup
+  const int tid = threadIdx.x, nthr = FIXED ? 64 : (int)blockDim.x;
+  if constexpr (FIXED) __builtin_assume(tid >= 0 && tid < 64);
+  const int lane = tid & 63, wave = FIXED ? 0 : tid >> 6, NW = FIXED ? 1 : nthr >> 6;
   const int slot = lane / LPS, li = lane - slot * LPS;   // segment slot in this wave, lane in segment
 
   R *Ts = sm;                // [MS]       segment_time
@@ -582,7 +592,12 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
     for (int w = tid; w < 3 * nseg; w += nthr) {
       const int S = w / 3, k = w - 3 * S;
       int tl = 0, s = S;
-      if constexpr (!ONE) while (s >= m) { s -= m; ++tl; }
+      if constexpr (TPBC == 2) {
+        tl = s >= m;
+        s -= tl * m;
+      } else if constexpr (!ONE) {
+        while (s >= m) { s -= m; ++tl; }
+      }
       const R *xk = a.x + (size_t)(b0 + tl) * n + k * ndp;    // free variables of axis k (:182-187)
       const R *df = a.Df + (size_t)(b0 + tl) * 18 + k * 6;    // [p,v,a]_start, [p,v,a]_end
       // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
@@ -624,7 +639,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
         dts[S] = T / (R)30.0;   // :351
         if (!do_colli) ccol[S] = (R)0;   // (aliases Ts: only when the sample phase will not read it)
       }
-      if constexpr (ONE) break;   // 3 m <= 18 work items: one trip
+      if constexpr (FIXED) break;   // 3 TPBC m <= 3 SPW <= 64 work items: one trip
     }
     __syncthreads();
     GTOP_STAMP(1);
@@ -885,7 +900,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
             __builtin_amdgcn_wave_barrier();
           }
         }
-        if constexpr (ONE) break;   // m <= SPW segments: one pass
+        if constexpr (FIXED) break;   // TPBC m <= SPW segments: one pass
       }
     } else {
       for (int q = tid; q < 18 * nseg; q += nthr) gseg[q] = Gs[q];   // |wc| < 1e-4: no collision term (:346)
@@ -902,7 +917,12 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
       R *fc = dts;   // [TPB]    cost copy (dts is dead after phase 2)
       for (int q = tid; q < ntraj * n; q += nthr) {
         int tl = 0, i = q;
-        if constexpr (!ONE) while (i >= n) { i -= n; ++tl; }
+        if constexpr (TPBC == 2) {
+          tl = i >= n;
+          i -= tl * n;
+        } else if constexpr (!ONE) {
+          while (i >= n) { i -= n; ++tl; }
+        }
         const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
         const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
         const R *gs = gseg + tl * m * 18;
@@ -937,18 +957,18 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
       }
     }
     GTOP_STAMP(6);
-    if constexpr (ONE && !MMA) break;   // nothing follows: no group, no pass
+    if constexpr (FIXED && !MMA) break;   // nothing follows: no group, no pass
     __syncthreads();   // LDS is reused by the next pass / the next group of this block
     }
-    if constexpr (ONE) break;   // the launcher gives every group its own workgroup
+    if constexpr (FIXED) break;   // the launcher gives every group its own workgroup
   }
 }
 
 }  // namespace
 
-size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem) {
+size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem, int red_rows) {
   const size_t MS = (size_t)tpb * m;
-  const size_t elems = MS + 18 * MS * 2 + 3 * MS + MS + (size_t)waves * kRedChunk * red_stride(spl);
+  const size_t elems = MS + 18 * MS * 2 + 3 * MS + MS + (size_t)waves * (red_rows > 0 ? red_rows : kRedChunkFull) * red_stride(spl);
   return elems * elem;
 }
 
@@ -962,30 +982,34 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 
 template <typename R, bool DYN, bool MMA, bool WIDE>
 static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, int grid,
-                             size_t smem, hipStream_t stream) {
+                             size_t smem /* of the generic body */, hipStream_t stream) {
   void (*kern)(const GtopKernelArgs<R>, const GtopMmaState) = nullptr;
-  // the specialised body for one wavefront = one whole trajectory (the small-batch geometry)
+  // the specialised straight-line bodies: one wavefront = one whole trajectory (SPL 3 or 6) or two (SPL 6)
   const int groups = (args.B + args.tpb - 1) / args.tpb;
-  const bool one = (spl == 3 || spl == 6) && waves == 1 && args.tpb == 1 && args.m >= 2 &&
-                   args.m <= gtop_eval_segments_per_wave(spl) &&
-                   grid == 8 * ((groups + 7) / 8);   // (no grid-stride loop in that body)
+  const bool fixed_ok = (spl == 3 || spl == 6) && waves == 1 && args.m >= 2 &&
+                        args.tpb * args.m <= gtop_eval_segments_per_wave(spl) &&
+                        grid == 8 * ((groups + 7) / 8);   // (no grid-stride loop in those bodies)
+  const bool one = fixed_ok && args.tpb == 1, two = fixed_ok && args.tpb == 2 && spl == 6 && !MMA;
+  if (two) smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R), red_chunk(sizeof(R), 2));   // its tile
   if constexpr (MMA) {   // the fused optimizer step is built for the geometries the auto rules pick
     switch (spl) {
-      case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE, false>; break;
-      case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, true, WIDE, true> : gtop_eval_kernel<R, DYN, 3, true, WIDE, false>; break;
-      case 6: kern = one ? gtop_eval_kernel<R, DYN, 6, true, WIDE, true> : gtop_eval_kernel<R, DYN, 6, true, WIDE, false>; break;
+      case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE, 0>; break;
+      case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, true, WIDE, 1> : gtop_eval_kernel<R, DYN, 3, true, WIDE, 0>; break;
+      case 6: kern = one ? gtop_eval_kernel<R, DYN, 6, true, WIDE, 1> : gtop_eval_kernel<R, DYN, 6, true, WIDE, 0>; break;
       default: return hipErrorInvalidValue;
     }
   } else {
     switch (spl) {
-      case 1: kern = gtop_eval_kernel<R, DYN, 1, false, WIDE, false>; break;
-      case 2: kern = gtop_eval_kernel<R, DYN, 2, false, WIDE, false>; break;
-      case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, false, WIDE, true> : gtop_eval_kernel<R, DYN, 3, false, WIDE, false>; break;
-      case 5: kern = gtop_eval_kernel<R, DYN, 5, false, WIDE, false>; break;
-      case 6: kern = one ? gtop_eval_kernel<R, DYN, 6, false, WIDE, true> : gtop_eval_kernel<R, DYN, 6, false, WIDE, false>; break;
-      case 10: kern = gtop_eval_kernel<R, DYN, 10, false, WIDE, false>; break;
-      case 15: kern = gtop_eval_kernel<R, DYN, 15, false, WIDE, false>; break;
-      case 30: kern = gtop_eval_kernel<R, DYN, 30, false, WIDE, false>; break;
+      case 1: kern = gtop_eval_kernel<R, DYN, 1, false, WIDE, 0>; break;
+      case 2: kern = gtop_eval_kernel<R, DYN, 2, false, WIDE, 0>; break;
+      case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, false, WIDE, 1> : gtop_eval_kernel<R, DYN, 3, false, WIDE, 0>; break;
+      case 5: kern = gtop_eval_kernel<R, DYN, 5, false, WIDE, 0>; break;
+      case 6: kern = one ? gtop_eval_kernel<R, DYN, 6, false, WIDE, 1>
+                         : (two ? gtop_eval_kernel<R, DYN, 6, false, WIDE, 2> : gtop_eval_kernel<R, DYN, 6, false, WIDE, 0>);
+              break;
+      case 10: kern = gtop_eval_kernel<R, DYN, 10, false, WIDE, 0>; break;
+      case 15: kern = gtop_eval_kernel<R, DYN, 15, false, WIDE, 0>; break;
+      case 30: kern = gtop_eval_kernel<R, DYN, 30, false, WIDE, 0>; break;
       default: return hipErrorInvalidValue;
     }
   }
