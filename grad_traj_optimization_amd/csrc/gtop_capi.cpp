@@ -158,11 +158,12 @@ void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int 
   int s = c->spl;
   // auto rule (measured): up to 256 trajectories a trajectory is spread over three wavefronts
   // (latency: one sample per lane); then one wavefront per trajectory, which for m <= 6 is the specialised
-  // straight-line body; the two-trajectories-per-wavefront body takes over once the GPU is several rounds deep
+  // straight-line body; the two-trajectories-per-wavefront body (4 wavefronts per SIMD) takes over from 8192
+  // trajectories (fp32: 4096)
   if (s == 0) {
     if (auto_spl) s = auto_spl;
     else if (B <= 256) s = 1;
-    else if (m <= 6) s = (B >= (f32 ? 12288 : 16384)) ? c->auto_spl_large : c->auto_spl_small;
+    else if (m <= 6) s = (B >= (f32 ? 4096 : 8192)) ? c->auto_spl_large : c->auto_spl_small;
     else s = (B >= 4096) ? c->auto_spl_large : c->auto_spl_small;
   }
   const int spw = gtop_eval_segments_per_wave(s);

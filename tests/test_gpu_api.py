@@ -233,7 +233,7 @@ def test_full_size_batch_properties(full_scene, oracle_mod, cfg):
     c2, g2 = ctx.eval_device(x[h:].contiguous(), Df[h:].contiguous(), T[h:].contiguous())
     cr, gr = ctx.eval_device(x.flip(0).contiguous(), Df.flip(0).contiguous(), T.flip(0).contiguous())
     torch.cuda.synchronize()
-    big = 16384 if dtype == "f64" else 12288
+    big = 8192 if dtype == "f64" else 4096
     bracket = lambda nb: 0 if nb <= 256 else (1 if nb < big else 2)   # the auto launch-geometry rule (m <= 6)
     if bracket(B // 2) == bracket(B):    # same geometry for the halves as for the whole: same summation order
         assert torch.equal(torch.cat([c1, c2]), c) and torch.equal(torch.cat([g1, g2]), g)
