@@ -76,9 +76,10 @@ constexpr int red_stride(int spl) {
 #define GTOP_RED_CHUNK 19
 #endif
 constexpr int kRedChunkFull = GTOP_RED_CHUNK;   // values per transpose-reduction pass
-// The fp64 two-trajectories-per-wavefront body fits 128 VGPRs; reducing in two passes of 10 rows
-// brings its LDS to 8.8 KB per workgroup, and 16 workgroups (4 wavefronts per SIMD) fit a CU.
-constexpr int red_chunk(size_t elem, int tpbc) { return (elem == 8 && tpbc == 2) ? 10 : kRedChunkFull; }
+// The specialised fp64 SPL = 6 bodies (one 40-control-point or two 20-control-point trajectories per
+// wavefront) fit 128 VGPRs; reducing in two passes of 10 rows brings their LDS to 8.8 KB per workgroup,
+// and 16 workgroups (4 wavefronts per SIMD) fit a CU.
+constexpr int red_chunk(size_t elem, int spl, int tpbc) { return (elem == 8 && spl == 6 && tpbc > 0) ? 10 : kRedChunkFull; }
 
 // Diagnostic build (-DGTOP_STAMPS): s_memtime at the phase boundaries of lane 0
 // of wave 0 of the first 4096 workgroups, into a buffer of its own that nothing
@@ -500,7 +501,7 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
 // the optional velocity/acceleration block (DYN) and the optimizer epilogue (MMA) more.  fp32: 3 waves; the
 // 128-VGPR budget of 4 waves spills.
 template <typename R, int SPL, bool DYN, bool MMA, int TPBC> struct MinWaves {
-  static constexpr int v = (!DYN && !MMA && SPL == 6 && TPBC == 2) ? 4
+  static constexpr int v = (!DYN && !MMA && SPL == 6 && TPBC > 0) ? 4
                            : (!DYN && !MMA && (SPL == 5 || SPL == 6)) ? GTOP_F64_MIN_WAVES_ROLLED : GTOP_F64_MIN_WAVES;
 };
 template <int SPL, bool DYN, bool MMA, int TPBC> struct MinWaves<float, SPL, DYN, MMA, TPBC> {
@@ -518,7 +519,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   constexpr int LPS = kSamples / SPL;        // lanes per segment
   constexpr int SPW = 64 / LPS;              // segments per wavefront
   constexpr int kRedStride = red_stride(SPL);
-  constexpr int kRedChunk = red_chunk(sizeof(R), TPBC);
+  constexpr int kRedChunk = red_chunk(sizeof(R), SPL, TPBC);
   // up to three samples per lane are unrolled outright (the small-batch geometry: one wavefront per SIMD,
   // the scheduler interleaves the samples); longer loops stay rolled to hold 2 waves per SIMD
   constexpr int kUnroll = (SPL <= 3 && !DYN) ? SPL : GTOP_SAMPLE_UNROLL;
@@ -989,8 +990,15 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
   const bool fixed_ok = (spl == 3 || spl == 6) && waves == 1 && args.m >= 2 &&
                         args.tpb * args.m <= gtop_eval_segments_per_wave(spl) &&
                         grid == 8 * ((groups + 7) / 8);   // (no grid-stride loop in those bodies)
-  const bool one = fixed_ok && args.tpb == 1, two = fixed_ok && args.tpb == 2 && spl == 6 && !MMA;
-  if (two) smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R), red_chunk(sizeof(R), 2));   // its tile
+  // A field that outgrows the 256 MB Infinity Cache is served by HBM; a fourth wavefront per SIMD then only
+  // adds L2 misses (measured at 400^3 fp64, m = 12: 47 us with the generic three-wavefront body, 52 us with
+  // four, 50 us with the specialised body held at three), so the SPL = 6 specialisations are for resident fields.
+  const unsigned long long field_bytes = (unsigned long long)args.nx * args.ny * args.nz * sizeof(R);
+  const bool resident = field_bytes <= (256ull << 20);
+  const bool one = fixed_ok && args.tpb == 1 && (spl == 3 || resident);
+  const bool two = fixed_ok && args.tpb == 2 && spl == 6 && !MMA && resident;
+  if (!MMA && spl == 6 && (one || two))   // their tile
+    smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R), red_chunk(sizeof(R), 6, args.tpb));
   if constexpr (MMA) {   // the fused optimizer step is built for the geometries the auto rules pick
     switch (spl) {
       case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE, 0>; break;
