@@ -11,24 +11,37 @@ variables), shared 200^3 distance field, fp64.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N
+ranks itself (fresh child processes, before this process touches a GPU) and
+relays rank 0's line.
+
 Multi-GPU: the batch shards across ranks (weak scaling: per-GPU batch fixed),
 the distance field is replicated, and the only collective is a bucketed RCCL
 all-gather of the per-trajectory costs (one collective per bucket of steps,
-overlapped with the next bucket's kernels).
+overlapped with the next bucket's kernels); --gather-grads adds the optional
+all-gather of each bucket's last gradient.
 
 Rank 0 prints ONE JSON line (contract in the task statement), extended with
 `roofline` (dominant kernel: gtop_eval_kernel, HBM-bound, algorithmic bytes
 of SURVEY.md §8d) and `cpu_baseline` (the oracle's C restatement timed on this
 box's host cores; N=1 only).
+
+Environment knobs for rehearsals on a one-GPU box (never set by the driver):
+  GTOP_BENCH_FORCE_DIST=1    initialise the process group (and run the
+                             collective) even at world size 1
+  GTOP_BENCH_BACKEND=gloo    collectives over gloo (staged through the host)
+  GTOP_BENCH_SHARE_DEVICE=1  every rank uses device 0 (RCCL refuses two ranks
+                             on one device, so only together with gloo)
+The JSON line then carries "rehearsal": true.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -36,20 +49,20 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+TOL = {"f64": 1e-5,     # BASELINE.json north_star
+       "f32": 2e-4}     # the bound tests/test_gpu_api.py holds the fp32 path to
 
 
 def measured_traffic(key):
     """HBM-side bytes per launch of gtop_eval_kernel for this workload, from the
     rocprofv3 --pmc passes committed under profiles/ (tools/pmc_collect.sh +
     tools/pmc_summary.py; counters cannot be read from inside this process).
-    None when this workload has not been profiled."""
+    {} when this workload has not been profiled."""
     try:
         with open(TRAFFIC_FILE) as f:
-            t = json.load(f)
-        return t.get(key)
+            return json.load(f).get(key) or {}
     except (OSError, ValueError):
-        return None
-
+        return {}
 
 
 def algorithmic_bytes(m, elem):
@@ -91,6 +104,8 @@ def parse():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--density", type=float, default=0.02)
     ap.add_argument("--bucket", type=int, default=50, help="steps per graph / per cost all-gather")
+    ap.add_argument("--gather-grads", action="store_true",
+                    help="also all-gather the gradient of each bucket's last step (a global optimizer step's input)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra workloads reported under 'extras'")
@@ -102,8 +117,52 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh
+    child processes (this parent has not imported torch, let alone touched a
+    GPU) and relay their exit code; rank 0's JSON line goes straight to the
+    inherited stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def parity_check(ctx, oracle, osdf, x, Df, T, host_rows, dtype, rows=256):
+    """HIP path vs the oracle on the first `rows` trajectories.  The WHOLE batch
+    is launched (so the kernel variant checked is the one that gets timed);
+    its first rows are compared.  host_rows = (T, Df, x) numpy, same order."""
+    import numpy as np
+    import torch
+    n = min(rows, x.shape[0])
+    c_dev, g_dev = ctx.eval_device(x, Df, T)
+    torch.cuda.synchronize()
+    Th, Dfh, xh = host_rows
+    c_ref, g_ref, _ = oracle.eval_batch(Th[:n], Dfh[:n], xh[:n], osdf, oracle.make_params(), nthreads=host_threads())
+    c = c_dev[:n].double().cpu().numpy()
+    g = g_dev[:n].double().cpu().numpy()
+    rc = float(np.max(np.abs(c - c_ref) / np.abs(c_ref)))
+    rg = float(np.max(np.max(np.abs(g - g_ref), axis=1) / np.max(np.abs(g_ref), axis=1)))
+    tol = TOL[dtype]
+    return {"n": n, "max_rel_cost": rc, "max_rel_grad": rg, "tol": tol, "ok": bool(rc <= tol and rg <= tol)}
+
+
+def oracle_field(oracle, mp, ctx):
+    osdf = oracle.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+    osdf.dist[:] = ctx.get_sdf().reshape(-1)
+    return osdf
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np  # noqa: F401  (used by helpers)
     import torch
     import torch.distributed as dist
     import grad_traj_optimization_amd as gtop
@@ -112,19 +171,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("GTOP_BENCH_BACKEND", "nccl")     # nccl == RCCL on ROCm
+    share_dev = os.environ.get("GTOP_BENCH_SHARE_DEVICE") == "1"
+    force_dist = os.environ.get("GTOP_BENCH_FORCE_DIST") == "1"
+    rehearsal = share_dev or backend != "nccl" or (force_dist and world == 1)
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
+    dev_index = 0 if share_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    collective = world > 1 or force_dist
+    if collective:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        kw = dict(device_id=dev) if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
 
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     elem = 8 if args.dtype == "f64" else 4
@@ -133,7 +202,7 @@ def main():
 
     # ---- synthetic inputs (same seeds on every rank; each rank keeps its shard) ----
     mp = problem.make_map(args.grid, density=args.density, seed=0)
-    ctx = gtop.GtopContext(device=local_rank)
+    ctx = gtop.GtopContext(device=dev_index)
     if args.waves or args.spl:
         ctx.set_launch_geometry(args.waves, args.spl)
     t0 = time.time()
@@ -155,46 +224,34 @@ def main():
     while args.steps % G:
         G -= 1
     nbuckets = args.steps // G
-    grad = torch.zeros(hi - lo, n, dtype=tdtype, device=dev)
 
     # ---- parity gate (rank 0): HIP vs oracle on a subsample of this rank's shard ----
     parity = None
+    osdf = None
     if rank == 0:
         from oracle import oracle
-        nchk = min(256, hi - lo)
-        # the whole shard, i.e. the launch geometry (kernel variant) that is timed below; its first rows are checked
-        c_dev, g_dev = ctx.eval_device(x, Df, T)
-        torch.cuda.synchronize()
-        c_dev, g_dev = c_dev[:nchk], g_dev[:nchk]
-        dist_host = ctx.get_sdf()
-        osdf = oracle.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
-        osdf.dist[:] = dist_host.reshape(-1)
-        c_ref, g_ref, _ = oracle.eval_batch(batch.T[lo:lo + nchk], batch.Df[lo:lo + nchk], batch.x[lo:lo + nchk],
-                                            osdf, oracle.make_params(), nthreads=host_threads())
-        c = c_dev.double().cpu().numpy()
-        gg = g_dev.double().cpu().numpy()
-        rc = float(np.max(np.abs(c - c_ref) / np.abs(c_ref)))
-        rg = float(np.max(np.max(np.abs(gg - g_ref), axis=1) / np.max(np.abs(g_ref), axis=1)))
-        tol = 1e-5 if args.dtype == "f64" else 5e-2
-        parity = {"n": nchk, "max_rel_cost": rc, "max_rel_grad": rg, "tol": tol, "ok": bool(rc <= tol and rg <= tol)}
+        osdf = oracle_field(oracle, mp, ctx)
+        parity = parity_check(ctx, oracle, osdf, x, Df, T, (batch.T[lo:hi], batch.Df[lo:hi], batch.x[lo:hi]),
+                              args.dtype)
         log(f"parity {parity}")
         if not parity["ok"]:
             print(f"bench.py: PARITY FAILED {parity}", file=sys.stderr)
             sys.exit(3)
 
-    # ---- launch plan: one hipGraph per cost ring buffer, G steps each ----
-    from grad_traj_optimization_amd.distributed import CostGatherPipeline
+    # ---- launch plan: one hipGraph per result ring buffer, G steps each ----
+    from grad_traj_optimization_amd.distributed import ResultGatherPipeline
     stream = torch.cuda.current_stream(dev)
     graphs = None
 
-    def run_bucket_eager(j):
-        for s in range(G):
-            ctx.eval_device(x, Df, T, pipe.cost_ring[j][s], grad)
+    def run_bucket_eager(j, steps=None):
+        for s in range(G if steps is None else steps):
+            ctx.eval_device(x, Df, T, pipe.cost_ring[j][s], pipe.grad_ring[j])
 
     def run_bucket_graph(j):
         graphs[j].replay()
 
-    pipe = CostGatherPipeline(world, rank, G, hi - lo, tdtype, dev, run_bucket_eager)
+    pipe = ResultGatherPipeline(world, rank, G, hi - lo, tdtype, dev, run_bucket_eager,
+                                n_free=n, gather_grads=args.gather_grads, collective=collective)
     launch_mode = "eager"
     if not args.no_graph:
         try:
@@ -212,18 +269,18 @@ def main():
             graphs = None
             torch.cuda.synchronize()
     if rank == 0:
-        log(f"launch mode {launch_mode}, {G} steps per bucket")
+        log(f"launch mode {launch_mode}, {G} steps per bucket, backend {backend if collective else 'none'}")
     run_bucket, drain = pipe.run_bucket, pipe.drain
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
 
-    # ---- warmup ----
-    wb = max(1, math.ceil(args.warmup / G)) if args.warmup > 0 else 0
-    for b in range(wb):
+    # ---- warmup: exactly W steps (whole buckets through the timed path, the rest as single launches) ----
+    for b in range(args.warmup // G):
         run_bucket(b)
     drain()
+    run_bucket_eager(0, args.warmup % G)
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K = nbuckets*G steps ----
@@ -242,13 +299,19 @@ def main():
     elapsed = t1 - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps     # avg per launch on the launch stream (HIP events)
 
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if collective:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        # every rank must now hold every rank's costs of the last bucket
+        # every rank must now hold every rank's costs (and gradients) of the last bucket
         last = pipe.all_costs(nbuckets - 1)
         assert torch.equal(last[rank], pipe.cost_ring[(nbuckets - 1) & 1])
+        if args.gather_grads:
+            assert torch.equal(pipe.all_grads(nbuckets - 1)[rank], pipe.grad_ring[(nbuckets - 1) & 1])
+        if rank == 0 and parity is not None:
+            # rank r's rows of the gathered costs are that rank's shard: check rank 0's against the parity launch
+            c_chk, _ = ctx.eval_device(x, Df, T)
+            assert torch.equal(last[0][-1], c_chk), "gathered costs differ from a direct evaluation"
 
     if rank == 0:
         log(f"timed region done: {elapsed:.4f} s for {args.steps} steps")
@@ -257,48 +320,59 @@ def main():
         wkey = f"B{Bl}_m{m}_g{args.grid}_{args.dtype}"
         bpe = algorithmic_bytes(m, elem)
         achieved = (hi - lo) * bpe / (kern_ms * 1e-3) / 1e9    # GB/s, per launch on this rank
+        is_cfg1 = (Bl, m, args.grid, args.dtype) == (1024, 6, 200, "f64")
+        par = "single GPU"
+        if world > 1:
+            par = (f"batch-sharded x{world}, SDF replicated, bucketed {'RCCL' if backend == 'nccl' else backend} "
+                   f"all-gather of costs" + (" + last gradient of each bucket" if args.gather_grads else ""))
         out = {
             "metric": "cost+grad evals/sec (batched trajectories)",
             "value": value, "unit": "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": wb * G,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {
                 "workload": f"B={Bl}/GPU x {m} segments ({3 * m + 3} ctrl pts, n={n}), {args.grid}^3 SDF, {args.dtype}"
-                            + (" [BASELINE.json configs[1]]" if (Bl, m, args.grid, args.dtype) == (1024, 6, 200, "f64") else ""),
+                            + (" [BASELINE.json configs[1]]" if is_cfg1 and world == 1 else "")
+                            + (" [BASELINE.json configs[3] at 8 ranks]" if Bl * world == 131072 and world == 8 else ""),
                 "batch_per_gpu": Bl, "global_batch": B_total, "segments": m, "free_vars": n,
                 "sdf_grid": [args.grid] * 3, "sdf_occupied_frac": float(mp.occupancy.mean()),
                 "params": "opti_node.launch (ws=1, wc=5, alpha=10, d0=0.8, r=0.5), step=2",
-                "parallelism": f"batch-sharded x{world}, SDF replicated, bucketed RCCL all-gather of costs"
-                               if world > 1 else "single GPU",
+                "parallelism": par,
                 "launch": launch_mode, "steps_per_bucket": G,
+                "collective_bytes_per_bucket": (world * G * (hi - lo) * elem
+                                                + (world * (hi - lo) * n * elem if args.gather_grads else 0))
+                                               if collective else 0,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "gtop_eval_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (measured_traffic(wkey) or {}).get("traffic_bytes"),
-                "traffic_source": (measured_traffic(wkey) or {}).get("source"),
+                "traffic": measured_traffic(wkey).get("traffic_bytes"),
+                "traffic_source": measured_traffic(wkey).get("source"),
                 "algorithmic_bytes_per_eval": bpe, "evals_per_launch": hi - lo,
                 "avg_launch_us": kern_ms * 1e3,
             },
             "parity": parity,
             "esdf_build_s": esdf_s,
         }
+        if rehearsal:
+            out["rehearsal"] = True
         if world == 1 and not args.no_extras:
+            from oracle import oracle
             try:   # untimed additions must never cost the main line
-                out["extras"] = extras(args, ctx, batch, mp, x, Df, T, tdtype, dev)
+                out["extras"] = extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev)
             except Exception as e:
                 out["extras"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, batch, mp, ctx)
+                out["cpu_baseline"] = cpu_baseline(args, batch, osdf)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 
@@ -318,10 +392,35 @@ def _time_evals(ctx, x, Df, T, reps):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-def extras(args, ctx, batch, mp, x, Df, T, tdtype, dev):
-    """Not part of `value`: (1) the other single-GPU BASELINE.json workloads on the
-    same map (eager launches, HIP-event time per launch), (2) the batched
-    optimizer driver on the bench batch."""
+def _extra_workload(ctx, oracle, osdf, b, m, grid, name, dev, label, reps=200):
+    """One more BASELINE.json workload: parity gate on 256 rows, then timed eager launches."""
+    import torch
+    dt = torch.float64 if name == "f64" else torch.float32
+    xb = torch.tensor(b.x, dtype=dt, device=dev)
+    Dfb = torch.tensor(b.Df.reshape(-1, 18), dtype=dt, device=dev)
+    Tb = torch.tensor(b.T, dtype=dt, device=dev)
+    B = xb.shape[0]
+    par = parity_check(ctx, oracle, osdf, xb, Dfb, Tb, (b.T, b.Df, b.x), name)
+    entry = {"workload": label, "parity": par}
+    if not par["ok"]:
+        entry["error"] = "parity gate failed; not timed"
+        return entry
+    us = _time_evals(ctx, xb, Dfb, Tb, reps)
+    bpe = algorithmic_bytes(m, 4 if name == "f32" else 8)
+    tr = measured_traffic(f"B{B}_m{m}_g{grid}_{name}")
+    entry.update({
+        "us_per_launch": us, "evals_per_s": B / (us * 1e-6),
+        "roofline": {"bound": "hbm", "achieved": B * bpe / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": B * bpe / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": tr.get("traffic_bytes"), "algorithmic_bytes_per_eval": bpe}})
+    return entry
+
+
+def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
+    """Not part of `value`: (1) the other single-GPU BASELINE.json workloads
+    (each behind its own 256-row parity gate; eager launches, HIP-event time
+    per launch), (2) the batched optimizer driver on the bench
+    batch."""
     import torch
     from grad_traj_optimization_amd import problem
     import grad_traj_optimization_amd as gtop
@@ -329,16 +428,25 @@ def extras(args, ctx, batch, mp, x, Df, T, tdtype, dev):
     if args.grid == 200 and args.segments == 6:
         big = problem.make_trajectories(16384, 6, mp, seed=7)
         big = problem.permute(big, problem.spatial_order(big.waypoints, mp.origin, mp.map_size))
-        for dt, name in ((torch.float32, "f32"), (torch.float64, "f64")):
-            xb = torch.tensor(big.x, dtype=dt, device=dev)
-            Dfb = torch.tensor(big.Df.reshape(-1, 18), dtype=dt, device=dev)
-            Tb = torch.tensor(big.T, dtype=dt, device=dev)
-            us = _time_evals(ctx, xb, Dfb, Tb, 200)
-            bpe = algorithmic_bytes(6, 4 if name == "f32" else 8)
-            out["workloads"].append({
-                "workload": f"B=16384 x 6 segments, 200^3 SDF, {name}" + (" [BASELINE.json configs[2]]" if name == "f32" else ""),
-                "us_per_launch": us, "evals_per_s": 16384 / (us * 1e-6),
-                "roofline_frac": 16384 * bpe / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        for name in ("f32", "f64"):
+            out["workloads"].append(_extra_workload(
+                ctx, oracle, osdf, big, 6, 200, name, dev,
+                f"B=16384 x 6 segments, 200^3 SDF, {name}" + (" [BASELINE.json configs[2]]" if name == "f32" else "")))
+        # configs[4]: 8 192 trajectories x 40 control points (m = 12), 400^3 field of mixed obstacle density
+        t0 = time.time()
+        mp4 = problem.make_map(400, density=0.04, seed=2)
+        ctx4 = gtop.GtopContext(device=ctx.device)
+        ctx4.init_sdf_map(mp4.map_size, mp4.origin, mp4.resolution)
+        ctx4.update_sdf_map(mp4.obstacle_points())
+        osdf4 = oracle_field(oracle, mp4, ctx4)
+        b4 = problem.make_trajectories(8192, 12, mp4, seed=3)
+        b4 = problem.permute(b4, problem.spatial_order(b4.waypoints, mp4.origin, mp4.map_size))
+        e4 = _extra_workload(ctx4, oracle, osdf4, b4, 12, 400, "f64", dev,
+                             "B=8192 x 12 segments (39 ctrl pts), 400^3 SDF, f64 [BASELINE.json configs[4]]")
+        e4["setup_s"] = time.time() - t0
+        out["workloads"].append(e4)
+        del osdf4
+        ctx4.close()
     if tdtype == torch.float64:
         lb, ub = gtop.GtopContext.default_bounds(batch.waypoints[:x.shape[0]])
         lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
@@ -373,13 +481,11 @@ def extras(args, ctx, batch, mp, x, Df, T, tdtype, dev):
     return out
 
 
-def cpu_baseline(args, batch, mp, ctx):
+def cpu_baseline(args, batch, osdf):
     """The oracle's C restatement (kind = "port": the reference itself cannot be
     built here) on a bounded sample of the SAME workload: single thread, as the
     reference's NLopt callback runs; an all-cores figure is added beside it."""
     from oracle import oracle
-    osdf = oracle.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
-    osdf.dist[:] = ctx.get_sdf().reshape(-1)
     prm = oracle.make_params()
     ns = min(256, batch.x.shape[0])
     Ts, Dfs, xs = batch.T[:ns], batch.Df[:ns], batch.x[:ns]

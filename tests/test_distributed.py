@@ -19,7 +19,7 @@ def _worker(rank, world, port, B, m, G, nbuckets, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from grad_traj_optimization_amd import problem
-    from grad_traj_optimization_amd.distributed import CostGatherPipeline, shard_range
+    from grad_traj_optimization_amd.distributed import ResultGatherPipeline, shard_range
     from oracle import oracle
 
     mpc = problem.make_map((24, 24, 16), density=0.04, seed=5)
@@ -34,17 +34,24 @@ def _worker(rank, world, port, B, m, G, nbuckets, out_dir):
         for s in range(G):
             # a different x per step so that stale buffers would be caught
             xs = batch.x[lo:hi] + 1e-3 * calls["n"]
-            c, _, _ = oracle.eval_batch(batch.T[lo:hi], batch.Df[lo:hi], xs, sdf, prm)
+            c, g, _ = oracle.eval_batch(batch.T[lo:hi], batch.Df[lo:hi], xs, sdf, prm)
             pipe.cost_ring[j][s].copy_(torch.from_numpy(c))
+            pipe.grad_ring[j].copy_(torch.from_numpy(g))
             calls["n"] += 1
 
-    pipe = CostGatherPipeline(world, rank, G, hi - lo, torch.float64, torch.device("cpu"), run_bucket)
-    seen = []
+    pipe = ResultGatherPipeline(world, rank, G, hi - lo, torch.float64, torch.device("cpu"), run_bucket,
+                                n_free=9 * (m - 1), gather_grads=True, collective=True)
+    seen, seen_g = [], []
     for b in range(nbuckets):
         pipe.run_bucket(b)
-        pipe.drain()
+        if b % 2:            # also leave a bucket in flight while the next one computes
+            pipe.drain()
+    pipe.drain()
+    for b in range(nbuckets - 2, nbuckets):    # the two ring slots still hold the last two buckets
         seen.append(pipe.all_costs(b).clone())
+        seen_g.append(pipe.all_grads(b).clone())
     np.save(os.path.join(out_dir, f"costs_rank{rank}.npy"), torch.stack(seen).numpy())
+    np.save(os.path.join(out_dir, f"grads_rank{rank}.npy"), torch.stack(seen_g).numpy())
     dist.destroy_process_group()
 
 
@@ -53,14 +60,31 @@ def test_two_rank_gather_equals_single_rank(tmp_path):
     B, m, G, nbuckets = 10, 4, 3, 3
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, B, m, G, nbuckets, str(tmp_path)), nprocs=2, join=True)
-    r0 = np.load(tmp_path / "costs_rank0.npy")   # (nbuckets, world, G, B/world)
+    r0 = np.load(tmp_path / "costs_rank0.npy")   # (2, world, G, B/world)
     r1 = np.load(tmp_path / "costs_rank1.npy")
-    assert np.array_equal(r0, r1)                 # every rank holds everything
+    g0 = np.load(tmp_path / "grads_rank0.npy")   # (2, world, B/world, n)
+    g1 = np.load(tmp_path / "grads_rank1.npy")
+    assert np.array_equal(r0, r1) and np.array_equal(g0, g1)   # every rank holds everything
     # single-rank reference of the same schedule
     mp.spawn(_worker, args=(1, port + 1, B, m, G, nbuckets, str(tmp_path)), nprocs=1, join=True)
-    s = np.load(tmp_path / "costs_rank0.npy")     # (nbuckets, 1, G, B)
+    s = np.load(tmp_path / "costs_rank0.npy")     # (2, 1, G, B)
+    sg = np.load(tmp_path / "grads_rank0.npy")    # (2, 1, B, n)
     two = np.concatenate([r0[:, 0], r0[:, 1]], axis=-1)
     assert np.array_equal(two, s[:, 0])           # bit-identical: partitioning only
+    assert np.array_equal(np.concatenate([g0[:, 0], g0[:, 1]], axis=1), sg[:, 0])
+
+
+def test_bench_starts_its_own_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` outside torchrun must start two ranks itself (fresh
+    children) — here, without a GPU, both report that and the code comes back."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("CPU-box check; the GPU box runs tests/test_gpu_multi.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                         capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode != 0
+    assert "torch.distributed.run" in out.stderr and out.stderr.count("bench.py needs a GPU") == 2
 
 
 def test_shard_range_partitions_exactly():

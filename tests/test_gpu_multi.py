@@ -1,0 +1,83 @@
+"""The N-rank bench path on ONE card: (1) RCCL initialised at world size 1 so
+that the process group, all_gather_into_tensor and hipGraph replay meet on
+hardware; (2) `bench.py --gpus 2` started directly (no torchrun): the
+self-launcher, two processes running the HIP kernels, collectives over gloo
+because RCCL refuses two ranks on one device; (3) one batch sharded over two
+gtop_ctx on device 0, bit-identical to the unsharded run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from grad_traj_optimization_amd import problem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _bench(args, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # exactly ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_rank_path_with_rccl_at_world_size_one():
+    r = _bench(["--gpus", "1", "--steps", "40", "--warmup", "7", "--bucket", "10", "--gather-grads",
+                "--no-extras", "--no-cpu-baseline"], {"GTOP_BENCH_FORCE_DIST": "1"})
+    assert r["rehearsal"] is True and r["n_gpus"] == 1
+    assert r["steps"] == 40 and r["warmup"] == 7           # --warmup honoured exactly
+    assert r["config"]["launch"] == "hipgraph" and r["config"]["steps_per_bucket"] == 10
+    assert r["config"]["collective_bytes_per_bucket"] == 10 * 1024 * 8 + 1024 * 45 * 8
+    assert r["parity"]["ok"] and r["value"] > 1e4
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launches_two_ranks_on_one_card():
+    r = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--batch", "512", "--gather-grads"],
+               {"GTOP_BENCH_BACKEND": "gloo", "GTOP_BENCH_SHARE_DEVICE": "1"})
+    assert r["rehearsal"] is True and r["n_gpus"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 1024 and r["config"]["batch_per_gpu"] == 512
+    assert r["parity"]["ok"] and r["value"] > 1e4
+    assert "extras" not in r and "cpu_baseline" not in r   # N = 1 only
+
+
+def test_two_contexts_on_one_device_equal_the_unsharded_batch(gtop):
+    """configs[3] in miniature: contiguous shards on separate contexts (each with its
+    own replicated field, built independently) and separate streams, no reduction
+    => bit-identical to one context evaluating the whole batch."""
+    import torch
+    mp = problem.make_map((80, 80, 40), density=0.03, seed=31)
+    b = problem.make_trajectories(2048, 6, mp, seed=32)
+    dev = torch.device("cuda:0")
+    ctxs = []
+    for _ in range(3):
+        c = gtop.GtopContext(device=0)
+        c.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+        c.update_sdf_map(mp.obstacle_points())
+        c.set_launch_geometry(1, 3)       # pin the kernel variant: shard size must not pick another summation order
+        ctxs.append(c)
+    assert np.array_equal(ctxs[0].get_sdf(), ctxs[1].get_sdf())
+    for td in (torch.float64, torch.float32):
+        x = torch.tensor(b.x, dtype=td, device=dev)
+        Df = torch.tensor(b.Df.reshape(-1, 18), dtype=td, device=dev)
+        T = torch.tensor(b.T, dtype=td, device=dev)
+        c_all, g_all = ctxs[2].eval_device(x, Df, T)
+        parts = []
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        for r in range(2):
+            lo, hi = problem.shard_range(2048, r, 2)
+            with torch.cuda.stream(streams[r]):
+                parts.append(ctxs[r].eval_device(x[lo:hi].contiguous(), Df[lo:hi].contiguous(),
+                                                 T[lo:hi].contiguous()))
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat([p[0] for p in parts]), c_all)
+        assert torch.equal(torch.cat([p[1] for p in parts]), g_all)
