@@ -349,6 +349,8 @@ int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
   const GtopGrid &g = c->grid;
   const size_t nvox = (size_t)g.nx * g.ny * g.nz;
   int rc;
+  // gtop_set_sdf may have moved the context to a larger grid since gtop_init_sdf_map sized the occupancy
+  if ((rc = ensure(c, &c->occ, &c->cap_occ, nvox))) return rc;
   if ((rc = ensure(c, &c->tmp1, &c->cap_tmp1, nvox))) return rc;
   if ((rc = ensure(c, &c->tmp2, &c->cap_tmp2, nvox))) return rc;
   if ((rc = ensure(c, &c->rows, &c->cap_rows, gtop_esdf_rows_ints(g)))) return rc;
@@ -514,6 +516,15 @@ int gtop_set_paths(gtop_ctx *c, int B, int m, const double *waypoints, double me
   if (!c) return GTOP_ERR_INVALID;
   if (B < 1 || m < 2 || !waypoints || !(mean_v > 0.0))
     return fail(c, GTOP_ERR_INVALID, "set_paths: need B >= 1, m >= 2 (3+ waypoints), mean_v > 0");
+  // same rule as gtop_set_problem: every segment time must be > 0.  Coincident consecutive waypoints give
+  // T_s = 0 (grad_traj_optimizer.cpp:73-81), a singular A_s in the reference and NaN here.
+  for (int b = 0; b < B; ++b)
+    for (int s = 0; s < m; ++s) {
+      const double *p = waypoints + ((size_t)b * (m + 1) + s) * 3;
+      const double dx = p[0] - p[3], dy = p[1] - p[4], dz = p[2] - p[5];
+      const double T = std::sqrt(dx * dx + dy * dy + dz * dz) / mean_v + (s == 0 ? init_time : 0.0);
+      if (!(T > 0.0)) return fail(c, GTOP_ERR_INVALID, "set_paths: coincident consecutive waypoints (segment time 0)");
+    }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = 9 * (size_t)(m - 1), nwp = (size_t)B * (m + 1) * 3;
   int rc;

@@ -123,7 +123,11 @@ int gtop_set_problem(gtop_ctx *ctx, int B, int m, const double *segment_time,
  * waypoints: B x (m+1) x 3.  gtop_set_paths makes the result the context's
  * problem (as gtop_set_problem would) and returns the start point x0 (B*n, may
  * be NULL); gtop_setup_paths_device writes device buffers and touches no state.
- * gtop_get_problem reads segment_time (B*m, or m when shared) and Df (B*18) back. */
+ * gtop_get_problem reads segment_time (B*m, or m when shared) and Df (B*18) back.
+ * gtop_set_paths rejects coincident consecutive waypoints (a segment time of 0:
+ * GTOP_ERR_INVALID, the rule gtop_set_problem applies); gtop_setup_paths_device
+ * cannot look at device memory without a synchronisation and behaves as the
+ * reference does there (T_s = 0, a singular A_s: NaN cost and gradient). */
 int gtop_set_paths(gtop_ctx *ctx, int B, int m, const double *waypoints,
                    double mean_v, double init_time, double *x0);
 int gtop_setup_paths_device(gtop_ctx *ctx, int B, int m, const void *d_waypoints,

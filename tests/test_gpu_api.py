@@ -161,6 +161,64 @@ def test_dyn_feasibility_flag(scene, oracle_mod):
     assert np.allclose(c_on, c_off, rtol=1e-14) and np.allclose(g_on, g_off, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("spl,B", [(1, 23), (3, 23), (3, 600), (6, 23), (6, 600), (6, 9000), (15, 23), (0, 9000)])
+def test_dyn_feasibility_every_body(scene, oracle_mod, dtype, spl, B):
+    """enable_dyn through every compiled body (grad_traj_optimizer.cpp:383-407, :517-535):
+    the three-wavefront SPL = 1 body, the straight-line one-trajectory bodies (SPL 3, 6), the
+    two-trajectories-per-wavefront body (SPL 6 from 8192 / 4096 rows), a rolled generic body
+    (SPL 15), in fp64 and packed fp32, with partial last workgroups (odd B)."""
+    import torch
+    mp, ctx, sdf = scene
+    td = torch.float64 if dtype == "f64" else torch.float32
+    tol = TOL64 if dtype == "f64" else TOL32
+    b = problem.make_trajectories(B, 6, mp, seed=300 + B)
+    p = dict(enable_dyn=1, alpha_v=2.0, alpha_a=1.5, step=2)
+    dev = torch.device("cuda:0")
+    x = torch.tensor(b.x, dtype=td, device=dev)
+    Df = torch.tensor(b.Df.reshape(-1, 18), dtype=td, device=dev)
+    T = torch.tensor(b.T, dtype=td, device=dev)
+    try:
+        ctx.set_params(**p)
+        ctx.set_launch_geometry(0, spl)
+        c, g = ctx.eval_device(x, Df, T)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_launch_geometry(0, 0)
+        ctx.set_params()
+    idx = np.arange(B) if B <= 600 else np.random.default_rng(5).choice(B, 300, replace=False)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(b.T[idx], b.Df[idx], b.x[idx], sdf, oracle_mod.make_params(**p),
+                                            nthreads=8)
+    rc, rg = scenes.rel_err(c[idx].double().cpu().numpy(), g[idx].double().cpu().numpy(), c_ref, g_ref)
+    assert rc <= tol and rg <= tol, (rc, rg)
+
+
+def test_set_sdf_to_a_larger_grid_then_update(gtop, oracle_mod):
+    """gtop_init_sdf_map(small) -> gtop_set_sdf(larger grid) -> gtop_update_sdf_map: the occupancy
+    workspace must follow the grid (it was sized by the init call only)."""
+    small = problem.make_map((16, 16, 8), density=0.03, seed=41)
+    large = problem.make_map((64, 48, 32), density=0.03, seed=42)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(small.map_size, small.origin, small.resolution)
+    ref = oracle_mod.Sdf.from_map_size(large.origin, large.resolution, large.map_size)
+    ref.build_from_occupancy(large.occupancy)
+    ctx.set_sdf(np.full(large.grid, 7.0), large.grid, large.origin, large.resolution, map_size=large.map_size)
+    ctx.update_sdf_map(large.obstacle_points())
+    assert np.array_equal(ctx.get_sdf().reshape(-1), ref.dist)
+
+
+def test_coincident_waypoints_are_rejected(gtop):
+    ctx = gtop.GtopContext(device=0)
+    wp = np.array([[[0, 0, 1], [1, 0, 1], [1, 0, 1], [2, 0, 1.0]]])     # segment 1 has length 0
+    with pytest.raises(gtop.GtopError) as e:
+        ctx.set_paths(wp)
+    assert e.value.code == 1
+    wp0 = np.array([[[0, 0, 1], [0, 0, 1], [1, 0, 1], [2, 0, 1.0]]])    # segment 0: init_time keeps T > 0
+    ctx.set_paths(wp0)
+    with pytest.raises(gtop.GtopError):
+        ctx.set_paths(wp0, init_time=0.0)
+
+
 def test_update_sdf_map_is_repeatable_and_resets(scene, oracle_mod):
     mp, ctx0, sdf = scene
     import grad_traj_optimization_amd as gtop
@@ -227,17 +285,25 @@ def test_full_size_batch_properties(full_scene, oracle_mod, cfg):
     c, g = ctx.eval_device(x, Df, T)
     torch.cuda.synchronize()
     assert torch.isfinite(c).all() and torch.isfinite(g).all() and (c >= 1e-3).all()
-    # halves + reversed order
-    h = B // 2
-    c1, g1 = ctx.eval_device(x[:h].contiguous(), Df[:h].contiguous(), T[:h].contiguous())
-    c2, g2 = ctx.eval_device(x[h:].contiguous(), Df[h:].contiguous(), T[h:].contiguous())
     cr, gr = ctx.eval_device(x.flip(0).contiguous(), Df.flip(0).contiguous(), T.flip(0).contiguous())
     torch.cuda.synchronize()
-    big = 8192 if dtype == "f64" else 4096
-    bracket = lambda nb: 0 if nb <= 256 else (1 if nb < big else 2)   # the auto launch-geometry rule (m <= 6)
-    if bracket(B // 2) == bracket(B):    # same geometry for the halves as for the whole: same summation order
-        assert torch.equal(torch.cat([c1, c2]), c) and torch.equal(torch.cat([g1, g2]), g)
     assert torch.equal(cr.flip(0), c) and torch.equal(gr.flip(0), g)
+    # halves vs whole, with the launch geometry pinned (the auto rule picks the body by batch size, and
+    # another body is another summation order): samples per lane 3 = one wavefront per trajectory
+    # whatever B, 6 = the one-trajectory body for the halves and the two-trajectory body for the whole
+    # when B is even -> both must still agree bit for bit within one pinned geometry at equal tpb
+    h = B // 2
+    try:
+        ctx.set_launch_geometry(1, 3)
+        cw, gw = ctx.eval_device(x, Df, T)
+        c1, g1 = ctx.eval_device(x[:h].contiguous(), Df[:h].contiguous(), T[:h].contiguous())
+        c2, g2 = ctx.eval_device(x[h:].contiguous(), Df[h:].contiguous(), T[h:].contiguous())
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_launch_geometry(0, 0)
+    assert torch.equal(torch.cat([c1, c2]), cw) and torch.equal(torch.cat([g1, g2]), gw)
+    tol_geo = 1e-12 if dtype == "f64" else 1e-4          # pinned vs auto geometry: summation order only
+    assert torch.max(torch.abs(cw - c) / torch.abs(c)).item() <= tol_geo
     # subsample against the oracle
     sdf = oracle_mod.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
     sdf.dist[:] = ctx.get_sdf().reshape(-1)

@@ -98,16 +98,20 @@ def test_default_bounds(gtop):
                     assert (lb[b, j], ub[b, j]) == (-10.0, 10.0)
 
 
-@pytest.mark.parametrize("m,evals", [(6, 25), (3, 40)])
-def test_device_lockstep_mma_follows_the_serial_algorithm(scene, oracle_mod, gtop, m, evals):
+@pytest.mark.parametrize("m,evals,kw", [(6, 25, {}), (3, 40, {}),
+                                        (6, 20, dict(enable_dyn=1, alpha_v=2.0, alpha_a=1.5))])   # MMA + DYN bodies
+def test_device_lockstep_mma_follows_the_serial_algorithm(scene, oracle_mod, gtop, m, evals, kw):
     mp, ctx, sdf = scene
     B = 12
     b = problem.make_trajectories(B, m, mp, seed=300 + m)
     lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
-    ctx.set_params()
+    ctx.set_params(**kw)
     ctx.set_problem(b.T, b.Df)
-    xs, costs = ctx.optimize_batch(b.x, lb, ub, evals)
-    prm = oracle_mod.make_params()
+    try:
+        xs, costs = ctx.optimize_batch(b.x, lb, ub, evals)
+    finally:
+        ctx.set_params()
+    prm = oracle_mod.make_params(**kw)
     c0, _, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, prm)
     for i in range(B):
         gen = oracle_mod.generator(b.T[i])
