@@ -292,6 +292,8 @@ def main():
     for b in range(nbuckets):
         run_bucket(b)
     ev1.record(stream)
+    while not ev1.query():     # poll: a blocking wait sleeps on an interrupt, tens of us after the last kernel ends
+        pass
     drain()
     torch.cuda.synchronize()
     barrier()

@@ -94,8 +94,20 @@ __device__ unsigned long long g_gtop_stamps[4096][16];
     __builtin_amdgcn_sched_barrier(0);                                                         \
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtop_stamps[blockIdx.x][i] = t_;              \
   } while (0)
+// where the wavefront runs (HW_ID: wave/simd/cu/sh/se; XCC_ID), into stamp slots 14 and 15
+#define GTOP_STAMP_HWID()                                                                      \
+  do {                                                                                         \
+    unsigned hw_, xcc_;                                                                        \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" \
+                 : "=s"(hw_), "=s"(xcc_));                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {                                               \
+      g_gtop_stamps[blockIdx.x][14] = hw_;                                                     \
+      g_gtop_stamps[blockIdx.x][15] = xcc_;                                                    \
+    }                                                                                          \
+  } while (0)
 #else
 #define GTOP_STAMP(i)
+#define GTOP_STAMP_HWID()
 #endif
 
 template <typename R> struct Pair { R x, y; } __attribute__((packed));
@@ -585,6 +597,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
     const int npass = MMA ? st.iters : 1;
     for (int pass = 0; pass < npass; ++pass) {
     GTOP_STAMP(0);
+    GTOP_STAMP_HWID();
     const int ntraj = ONE ? 1 : min(TPB, a.B - b0);   // trajectories this pass
     const int nseg = ntraj * m;             // live virtual segments
     // ---- phase 1: per (segment, axis): coefficients, jerk cost and jerk gradient ----
@@ -965,6 +978,250 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// gtop_eval_wave_kernel — one wavefront = NT whole trajectories, nothing shared
+// between wavefronts, the whole evaluation as ONE dependent chain without a
+// workgroup barrier.  Built for the latency regime (a batch of about one
+// wavefront per SIMD: the bench default, 1 024 x 20 control points), where a
+// lone wavefront pays four cycles per instruction of any kind and every round
+// trip is exposed, so the design removes phases rather than overlapping them:
+//   * no phase 1: every lane of a segment loads the segment's seven inputs per
+//     axis itself (the 10 lanes of a segment read the same addresses: one
+//     request) and forms the 18 polynomial coefficients in registers — no LDS
+//     staging, no barrier, no per-sample LDS reads;
+//   * the jerk term rides in the accumulators: its gradient is linear in the
+//     coefficients, so lane 0 of each segment STARTS its 18 coefficient-space
+//     accumulators at ws*2Qc (and its cost accumulator at ws*c'Qc) instead of
+//     zero; the A_s^-T applied after the samples (linear) takes it to
+//     derivative space together with the collision gradient;
+//   * one LDS round trip: the lanes write their 18 values to a tile, and the
+//     lane that owns free variable i sums the 2*LPS entries that make it up
+//     (end of segment w-1 + start of segment w) straight from the tile, adds
+//     1e-5 and stores; the scalar cost is a DPP wavefront sum of the lanes'
+//     cost accumulators, no LDS at all.
+// Same arithmetic as gtop_eval_kernel sample for sample; only the order of the
+// final sums differs (measured against the oracle: <= 1e-12).
+// Host-checked: NT*m <= 64/LPS, one workgroup per group of NT trajectories.
+// ---------------------------------------------------------------------------
+template <typename R, bool WIDE, int SPL, int NT>
+__global__ void __launch_bounds__(64) gtop_eval_wave_kernel(const GtopKernelArgs<R> a) {
+  constexpr int LPS = kSamples / SPL;   // lanes per segment
+  constexpr int SPW = 64 / LPS;         // segment slots per wavefront
+  constexpr int kStride = red_stride(SPL);
+  static_assert(SPL <= 3, "samples of a lane are unrolled");
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  R *tile = reinterpret_cast<R *>(smem_raw);   // [18][kStride]
+  const int lane = threadIdx.x;
+  const int m = a.m, ndp = 3 * m - 3, n = 3 * ndp;
+  __builtin_assume(m >= 2 && NT * m <= SPW);
+  __builtin_assume(lane >= 0 && lane < 64);
+
+  // XCD-aware order (see gtop_eval_kernel): XCD x gets the x-th contiguous eighth of the batch
+  const int ngroups = (a.B + NT - 1) / NT;
+  const int per_xcd = (ngroups + 7) >> 3;
+  // The grid is 8*per_xcd workgroups; the up to 7 beyond the batch take no early exit (a branch here would
+  // split the kernel-argument loads into two dependent round trips): they shadow the last group with every
+  // lane idle and every store predicated off.
+  const int grp_raw = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  const bool grp_ok = grp_raw < ngroups;
+  const int grp = grp_ok ? grp_raw : ngroups - 1;
+  const int b0 = grp * NT;
+
+  const int slot = lane / LPS, li = lane - slot * LPS;
+  int tl = 0, s = slot;
+  if constexpr (NT == 2) {
+    tl = s >= m;
+    s -= tl * m;
+  }
+  const bool seg_ok = grp_ok & (slot < NT * m) & (b0 + tl < a.B);
+  if (!seg_ok) { tl = 0; s = 0; }   // idle lanes shadow the first segment: finite data, results never read
+
+  // ---- inputs: two waypoints' (p, v, a) per axis and T_s, straight from HBM/L2 ----
+  // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
+  const R *xb = a.x + (size_t)b0 * n;      // wave-uniform bases
+  const R *dfb = a.Df + (size_t)b0 * 18;
+  const R T = a.T[(size_t)b0 * a.t_stride + tl * a.t_stride + s];
+  R w0[3][3], w1[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const R *df = dfb + tl * 18 + k * 6;
+    const R *xk = xb + tl * n + k * ndp;      // free variables of axis k (:182-187)
+    const R *p0 = (s == 0) ? df : xk + 3 * (s - 1);
+    const R *p1 = (s + 1 == m) ? df + 3 : xk + 3 * s;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      w0[k][i] = p0[i];
+      w1[k][i] = p1[i];
+    }
+  }
+
+  const R ws = (a.step == 1) ? (R)0 : a.ws;   // :412-415
+  const R wc = a.wc;
+  const bool do_colli = !(gabs(wc) < (R)1e-4);   // :346
+  ExpConsts expk;
+  R pen_d0 = a.d0, pen_inv_r = a.inv_r, pen_alpha = a.alpha, pen_gd = -a.alpha_over_r;   // (:507-515)
+  MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
+                      {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
+  if constexpr (!kIsF32<R>) {
+    expk.pin();
+    mapbox.pin();
+  }
+
+  // ---- coefficients c = A_s^-1 d (closed form; rows of A_s: src/qp_generator.cpp:185-195) ----
+  const R T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+  const R iT = fast_rcp(T), iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
+  const R dt = T / (R)30.0;   // :351
+  const R wdt = wc * dt;
+  R q[3][6];
+  R acc[kRedVals];
+  {
+    // jerk Hessian Q_s (src/qp_generator.cpp:226-234), i,j in {3,4,5}
+    const R Q33 = (R)36 * T, Q34 = (R)72 * T2, Q35 = (R)120 * T3, Q44 = (R)192 * T3, Q45 = (R)360 * T4,
+            Q55 = (R)720 * T5;
+    // lane 0 of a segment carries the segment's jerk term into the sums
+    const R wj = (seg_ok & (li == 0)) ? ws : (R)0;
+    const R wj2 = wj + wj;
+    R jc = (R)0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const R p0 = w0[k][0], v0 = w0[k][1], a0 = w0[k][2];
+      const R pT = w1[k][0], vT = w1[k][1], aT = w1[k][2];
+      const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
+      const R V = (vT - v0 - a0 * T) * T;
+      const R A = (aT - a0) * T2;
+      const R c3 = ((R)10 * P - (R)4 * V + (R)0.5 * A) * iT3;
+      const R c4 = ((R)-15 * P + (R)7 * V - A) * iT4;
+      const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) * iT5;
+      q[k][0] = p0; q[k][1] = v0; q[k][2] = (R)0.5 * a0; q[k][3] = c3; q[k][4] = c4; q[k][5] = c5;
+      const R q3 = Q33 * c3 + Q34 * c4 + Q35 * c5;
+      const R q4 = Q34 * c3 + Q44 * c4 + Q45 * c5;
+      const R q5 = Q35 * c3 + Q45 * c4 + Q55 * c5;
+      jc += c3 * q3 + c4 * q4 + c5 * q5;   // c'Qc: this (s,k)'s share of d'Rd (:326-327)
+      // ws * 2Qc: share of ws*(2Rfp'df + 2Rpp dp) (:330-336) in coefficient space (entries 0..2 are zero)
+      acc[6 * k + 0] = (R)0; acc[6 * k + 1] = (R)0; acc[6 * k + 2] = (R)0;
+      acc[6 * k + 3] = wj2 * q3; acc[6 * k + 4] = wj2 * q4; acc[6 * k + 5] = wj2 * q5;
+    }
+    acc[18] = wj * jc;
+  }
+
+  // ---- collision samples (:345-409); sample index = li + j*LPS ----
+  if (do_colli) {
+    // Sample times (:353, see gtop_eval_kernel): t_i = 1e-3 + i*dt; segments with T < 0.0301 (where the
+    // sample COUNT depends on the accumulated value) replay the reference's addition chain.
+    R ts[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) ts[j] = (R)(li + j * LPS) * dt + (R)1e-3;
+    const bool tiny_T = T < (R)0.0301;
+    if (__ballot(tiny_T) != 0ull) {   // wave-uniform, rare
+      if (tiny_T) {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+          R t = (R)1e-3;
+          for (int i = 0; i < li + j * LPS; ++i) t += dt;
+          ts[j] = t;
+        }
+      }
+    }
+    // stage A: positions, index arithmetic, all corner loads in flight
+    R vels[SPL][3];
+    bool lives[SPL];
+    SdfTap<R> taps[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      const R t = ts[j];
+      lives[j] = seg_ok & (t < T);   // the loop condition of :353
+      const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+      const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;   // d/dt of the powers
+      R pos[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        // :457-465 / :477-485 (sums in the reference's order), then the float round trip
+        pos[k] = round_through_float(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
+        vels[j][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
+      }
+      taps[j] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
+    }
+    // stage B: trilinear blend, penalty, accumulation
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      const R t = ts[j];
+      const R *vel = vels[j];
+      const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+      const R vn = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;   // :358
+      const R ivn = quick_rcp(vn);
+      R g3[3];
+      bool is_out;
+      const R dist = sdf_blend(taps[j], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
+      const R e = lives[j] ? penalty_exp((pen_d0 - dist) * pen_inv_r, expk) : (R)0;   // exp(-(d - d0)/r)
+      const R cd = pen_alpha * e;   // :509
+      const R gd = pen_gd * e;      // :514
+      acc[18] += wdt * (cd * vn);   // :373, weighted as in :417-418
+      // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
+      const R f1 = is_out ? (R)0 : (wdt * a.res_inv) * (gd * cd * vn), f2 = wdt * (cd * ivn);
+      const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const R w1k = f1 * g3[k], w2k = f2 * vel[k];
+        R *ak = acc + 6 * k;
+        ak[0] += w1k;
+        ak[1] = gfma(w1k, t, ak[1] + w2k);
+        ak[2] = gfma(w1k, t2, gfma(w2k, d2, ak[2]));
+        ak[3] = gfma(w1k, t3, gfma(w2k, d3, ak[3]));
+        ak[4] = gfma(w1k, t4, gfma(w2k, d4, ak[4]));
+        ak[5] = gfma(w1k, t5, gfma(w2k, d5, ak[5]));
+      }
+    }
+  }
+
+  // ---- A_s^-T on the lane's 18 accumulators: coefficient space -> [p0,pT,v0,vT,a0,aT] per axis ----
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    R *g = acc + 6 * k;
+    const R H3 = g[3] * iT3, H4 = g[4] * iT4, H5 = g[5] * iT5;
+    const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
+    const R o0 = g[0] - ap;
+    const R o2 = g[1] + T * ((R)-6 * H3 + (R)8 * H4 - (R)3 * H5);
+    const R o3 = T * ((R)-4 * H3 + (R)7 * H4 - (R)3 * H5);
+    const R o4 = (R)0.5 * g[2] + T2 * ((R)-1.5 * H3 + (R)1.5 * H4 - (R)0.5 * H5);
+    const R o5 = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
+    g[0] = o0; g[1] = ap; g[2] = o2; g[3] = o3; g[4] = o4; g[5] = o5;
+  }
+
+  // ---- the one LDS round trip: tile[v][lane], then each free variable sums its 2*LPS entries ----
+  if (lane < LPS * SPW) {
+#pragma unroll
+    for (int v = 0; v < 18; ++v) tile[v * kStride + lane] = acc[v];   // (idle lanes hold exact zeros: e = wj = 0)
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
+  __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
+#pragma unroll
+  for (int r = 0; r < (NT * 9 * (SPW / NT - 1) + 63) / 64; ++r) {
+    const int qi = lane + 64 * r;
+    int tq = 0, i = qi;
+    if constexpr (NT == 2) {
+      tq = i >= n;
+      i -= tq * n;
+    }
+    const bool ok = grp_ok & (qi < NT * n) & (b0 + tq < a.B);
+    const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
+    const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
+    // free variable = end of segment wpt-1 (entry 2 der + 1) + start of segment wpt (entry 2 der)  (:425-432)
+    const int rowA = axis * 6 + 2 * der + 1, rowB = axis * 6 + 2 * der;
+    const int sA = tq * m + wpt - 1;
+    const R *colA = tile + (ok ? rowA * kStride + sA * LPS : 0);
+    const R *colB = tile + (ok ? rowB * kStride + (sA + 1) * LPS : 0);
+    const R v = tree_sum<R, LPS>(colA) + tree_sum<R, LPS>(colB);
+    if (ok) a.grad[(size_t)b0 * n + qi] = v + (R)1e-5;
+  }
+  // ---- cost (:417-418): every term is already weighted; wavefront sum on the DPP path ----
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const bool mine = seg_ok & (NT == 1 || tl == t);
+    const R total = wave_sum(mine ? acc[18] : (R)0);
+    if (grp_ok & (lane == 0) & (b0 + t < a.B)) a.cost[b0 + t] = total + (R)1e-3;
+  }
+}
+
 }  // namespace
 
 size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem, int red_rows) {
@@ -999,6 +1256,16 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
   const bool two = fixed_ok && args.tpb == 2 && spl == 6 && !MMA && resident;
   if (!MMA && spl == 6 && (one || two))   // their tile
     smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R), red_chunk(sizeof(R), 6, args.tpb));
+#ifndef GTOP_WAVE_KERNEL
+#define GTOP_WAVE_KERNEL 1
+#endif
+  if constexpr (GTOP_WAVE_KERNEL && !MMA && !DYN) {
+    if (one && spl == 3) {   // one wavefront per trajectory: the barrier-free chain
+      hipLaunchKernelGGL((gtop_eval_wave_kernel<R, WIDE, 3, 1>), dim3(grid), dim3(64),
+                         18 * red_stride(3) * sizeof(R), stream, args);
+      return hipGetLastError();
+    }
+  }
   if constexpr (MMA) {   // the fused optimizer step is built for the geometries the auto rules pick
     switch (spl) {
       case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE, 0>; break;

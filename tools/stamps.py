@@ -50,3 +50,15 @@ print("  fine (first sample chunk): start->issued %.0f, issued->loads landed %.0
 print("  fine: samples end->tile written %.0f, tile->sums %.0f, sums->barrier %.0f; phase4: gradient scatter %.0f, cost %.0f" % (
     np.median(f[:, 11] - f[:, 3]), np.median(f[:, 12] - f[:, 11]), np.median(f[:, 4] - f[:, 12]),
     np.median(f[:, 13] - f[:, 5]), np.median(f[:, 6] - f[:, 13])))
+
+# placement: how many of the launch's wavefronts shared a SIMD (HW_ID bits: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13)
+hw = buf[:nb, 14].astype(np.int64)
+xcc = buf[:nb, 15].astype(np.int64) & 0xF
+simd_key = (xcc << 20) | (((hw >> 13) & 7) << 16) | (((hw >> 12) & 1) << 15) | (((hw >> 8) & 15) << 4) | ((hw >> 4) & 3)
+uniq, cnt = np.unique(simd_key, return_counts=True)
+print(f"  placement: {nb} workgroups on {len(uniq)} distinct SIMDs; workgroups per SIMD histogram "
+      f"{dict(zip(*np.unique(cnt, return_counts=True)))}; XCC histogram {dict(zip(*np.unique(xcc, return_counts=True)))}")
+tot = s[:, 6] - s[:, 0]
+for c in np.unique(cnt):
+    sel = np.isin(simd_key, uniq[cnt == c])
+    print(f"    SIMDs holding {c} workgroup(s): median kernel-body cycles {np.median(tot[sel]):.0f}")
