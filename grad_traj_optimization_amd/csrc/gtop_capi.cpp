@@ -200,7 +200,8 @@ void fill_args(const gtop_ctx *c, GtopKernelArgs<R> &a) {
 
 template <typename R>
 int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const void *d_Df,
-                const void *d_T, int t_stride, void *d_cost, void *d_grad, hipStream_t stream) {
+                const void *d_T, int t_stride, void *d_cost, void *d_grad, hipStream_t stream,
+                bool wave_kernel_ok = true) {
   GtopKernelArgs<R> a;
   fill_args(c, a);
   a.sdf = sdf;
@@ -216,7 +217,7 @@ int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const 
   a.tpb = tpb;
   if (gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(R)) > 160 * 1024)
     return fail(c, GTOP_ERR_INVALID, "m too large for one workgroup's LDS");
-  HIPCHK(c, gtop_launch_eval<R>(a, waves, spl, c->prm.enable_dyn != 0, 1 << 20, stream));
+  HIPCHK(c, gtop_launch_eval<R>(a, waves, spl, c->prm.enable_dyn != 0, 1 << 20, stream, wave_kernel_ok));
   return GTOP_OK;
 }
 
@@ -711,7 +712,8 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
       a.tpb = tpb;
       HIPCHK(c, gtop_launch_eval_mma(a, st, waves, spl, c->prm.enable_dyn != 0, 1 << 20, s));
     } else {
-      if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s)))
+      if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s,
+                                    /*wave_kernel_ok=*/false)))   // the body the fused modes run: same bits
         return rc;
       HIPCHK(c, gtop_launch_mma_update(st, B, (int)n, c->mma_f, c->mma_g, s));
     }

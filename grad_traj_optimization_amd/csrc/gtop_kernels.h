@@ -46,9 +46,11 @@ size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem, int
 // spl = samples per lane (a divisor of 30); a wavefront then holds
 // gtop_eval_segments_per_wave(spl) segments.
 int gtop_eval_segments_per_wave(int spl);
+// wave_kernel_ok = false keeps the launch on gtop_eval_kernel where gtop_eval_wave_kernel would serve it (the
+// optimizer's separate-update mode: same body, hence the same bits, as its fused modes).
 template <typename R>
 hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
-                            int max_blocks, hipStream_t stream);
+                            int max_blocks, hipStream_t stream, bool wave_kernel_ok = true);
 
 hipError_t gtop_launch_f64_to_f32(const double *src, float *dst, size_t nelem,
                                   hipStream_t stream);

@@ -110,6 +110,19 @@ __device__ unsigned long long g_gtop_stamps[4096][16];
 #define GTOP_STAMP_HWID()
 #endif
 
+// Diagnostic (-DGTOP_MARKS): comment markers in the ISA at region boundaries of gtop_eval_wave_kernel (pinned with
+// scheduling barriers) so that instructions can be counted per region with tools/isa_regions.py.
+#ifdef GTOP_MARKS
+#define GTOP_MARK(n)                                \
+  do {                                              \
+    __builtin_amdgcn_sched_barrier(0);              \
+    asm volatile("; GTOP_MARK " #n ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);              \
+  } while (0)
+#else
+#define GTOP_MARK(n)
+#endif
+
 template <typename R> struct Pair { R x, y; } __attribute__((packed));
 template <typename R> constexpr bool kIsF32 = false;
 template <> constexpr bool kIsF32<float> = true;
@@ -1003,18 +1016,36 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
 // final sums differs (measured against the oracle: <= 1e-12).
 // Host-checked: NT*m <= 64/LPS, one workgroup per group of NT trajectories.
 // ---------------------------------------------------------------------------
-template <typename R, bool WIDE, int SPL, int NT>
-__global__ void __launch_bounds__(64) gtop_eval_wave_kernel(const GtopKernelArgs<R> a) {
+// COLLI = false is the |wc| < 1e-4 case (:346, no collision term), decided by the launcher: the kernel body is
+// then one basic block, in which the order the phases are written in can be held (scheduling barriers).
+//
+// Kernel arguments: what the first loads need (three input pointers, B, m, the time stride) and the field
+// descriptor come as leading scalar arguments, which the build preloads into SGPRs at wavefront launch
+// (-amdgpu-kernarg-preload-count, csrc/Makefile): measured with s_memtime stamps, a lone wavefront otherwise
+// waits ~1 100 cycles for its kernel-argument fetch before it can even request its inputs.  The rest of the
+// arguments (`a`; its x/Df/T/sdf/B/m/t_stride/nx/ny/nz fields are not read) arrive while the inputs do.
+template <typename R, bool WIDE, int SPL, int NT, bool COLLI>
+__global__ void __launch_bounds__(64)
+gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df, const R *__restrict__ arg_T,
+                      const R *__restrict__ arg_sdf, int arg_B, int arg_m, int arg_t_stride, int arg_nx, int arg_ny,
+                      int arg_nz, const GtopKernelArgs<R> arg_rest) {
+  GtopKernelArgs<R> a = arg_rest;
+  a.x = arg_x; a.Df = arg_Df; a.T = arg_T; a.sdf = arg_sdf;
+  a.B = arg_B; a.m = arg_m; a.t_stride = arg_t_stride;
+  a.nx = arg_nx; a.ny = arg_ny; a.nz = arg_nz;
   constexpr int LPS = kSamples / SPL;   // lanes per segment
   constexpr int SPW = 64 / LPS;         // segment slots per wavefront
   constexpr int kStride = red_stride(SPL);
   static_assert(SPL <= 3, "samples of a lane are unrolled");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);   // [18][kStride]
+  GTOP_STAMP(0);
+  GTOP_STAMP_HWID();
   const int lane = threadIdx.x;
   const int m = a.m, ndp = 3 * m - 3, n = 3 * ndp;
   __builtin_assume(m >= 2 && NT * m <= SPW);
   __builtin_assume(lane >= 0 && lane < 64);
+  GTOP_STAMP(1);
 
   // XCD-aware order (see gtop_eval_kernel): XCD x gets the x-th contiguous eighth of the batch
   const int ngroups = (a.B + NT - 1) / NT;
@@ -1038,44 +1069,86 @@ __global__ void __launch_bounds__(64) gtop_eval_wave_kernel(const GtopKernelArgs
 
   // ---- inputs: two waypoints' (p, v, a) per axis and T_s, straight from HBM/L2 ----
   // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
-  const R *xb = a.x + (size_t)b0 * n;      // wave-uniform bases
-  const R *dfb = a.Df + (size_t)b0 * 18;
+  const R *xb = a.x + (size_t)b0 * n + tl * n;      // this lane's trajectory (b0: wave-uniform)
+  const R *dfb = a.Df + (size_t)b0 * 18 + tl * 18;
   const R T = a.T[(size_t)b0 * a.t_stride + tl * a.t_stride + s];
+  // axis 0: the (p, v, a) triple at the segment's start and at its end; the other axes are one per-lane stride
+  // further (6 within Df, 3m-3 within x: :182-187)
+  const bool first = s == 0, last = s + 1 == m;
+  const R *p0 = first ? dfb : xb + 3 * (s - 1);
+  const R *p1 = last ? dfb + 3 : xb + 3 * s;
+  const int st0 = first ? 6 : ndp, st1 = last ? 6 : ndp;
   R w0[3][3], w1[3][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const R *df = dfb + tl * 18 + k * 6;
-    const R *xk = xb + tl * n + k * ndp;      // free variables of axis k (:182-187)
-    const R *p0 = (s == 0) ? df : xk + 3 * (s - 1);
-    const R *p1 = (s + 1 == m) ? df + 3 : xk + 3 * s;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      w0[k][i] = p0[i];
-      w1[k][i] = p1[i];
+      w0[k][i] = p0[k * st0 + i];
+      w1[k][i] = p1[k * st1 + i];
     }
   }
 
-  const R ws = (a.step == 1) ? (R)0 : a.ws;   // :412-415
+  // Where this lane's free variable(s) will be summed from at the very end (index arithmetic done here, while
+  // the inputs are on their way): free variable = end of segment wpt-1 (entry 2 der + 1) + start of segment
+  // wpt (entry 2 der)  (:425-432); tile[v][lane] holds entry v of lane's segment.
+  constexpr int kRounds = (NT * 9 * (SPW / NT - 1) + 63) / 64;
+  int offA[kRounds], offB[kRounds];
+  bool okq[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int qi = lane + 64 * r;
+    int tq = 0, i = qi;
+    if constexpr (NT == 2) {
+      tq = i >= n;
+      i -= tq * n;
+    }
+    okq[r] = grp_ok & (qi < NT * n) & (b0 + tq < a.B);
+    const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
+    const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
+    const int rowB = axis * 6 + 2 * der;
+    const int sA = tq * m + wpt - 1;
+    offA[r] = okq[r] ? (rowB + 1) * kStride + sA * LPS : 0;
+    offB[r] = okq[r] ? rowB * kStride + (sA + 1) * LPS : 0;
+  }
+  const R ws = a.ws;   // the launcher has applied :412-415 (step 1 -> ws = 0): `step` is not read here
   const R wc = a.wc;
-  const bool do_colli = !(gabs(wc) < (R)1e-4);   // :346
   ExpConsts expk;
   R pen_d0 = a.d0, pen_inv_r = a.inv_r, pen_alpha = a.alpha, pen_gd = -a.alpha_over_r;   // (:507-515)
   MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
                       {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
-  if constexpr (!kIsF32<R>) {
+  if constexpr (COLLI && !kIsF32<R>) {
     expk.pin();
     mapbox.pin();
   }
-
+#ifdef GTOP_STAMPS
+  GTOP_STAMP(2);   // inputs requested
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GTOP_STAMP(3);   // inputs landed
+#endif
   // ---- coefficients c = A_s^-1 d (closed form; rows of A_s: src/qp_generator.cpp:185-195) ----
   const R T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
   const R iT = fast_rcp(T), iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
-  const R dt = T / (R)30.0;   // :351
+  // :351, dt = T/30.  The quotient proper (a dozen instructions) is only needed where the sample COUNT hangs on
+  // the accumulated sample time (tiny T, below); everywhere else T * (1/30) is the same to an ulp.
+  R dt = T * (R)(1.0 / 30.0);
   const R wdt = wc * dt;
   R q[3][6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const R p0 = w0[k][0], v0 = w0[k][1], a0 = w0[k][2];
+    const R pT = w1[k][0], vT = w1[k][1], aT = w1[k][2];
+    const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
+    const R V = (vT - v0 - a0 * T) * T;
+    const R A = (aT - a0) * T2;
+    q[k][0] = p0; q[k][1] = v0; q[k][2] = (R)0.5 * a0;
+    q[k][3] = ((R)10 * P - (R)4 * V + (R)0.5 * A) * iT3;
+    q[k][4] = ((R)-15 * P + (R)7 * V - A) * iT4;
+    q[k][5] = ((R)6 * P - (R)3 * V + (R)0.5 * A) * iT5;
+  }
+  // The jerk term, as the START value of the accumulators (a lambda: it is placed where the distance-field
+  // loads are in flight, see below).  Jerk Hessian Q_s: src/qp_generator.cpp:226-234, i,j in {3,4,5}.
   R acc[kRedVals];
-  {
-    // jerk Hessian Q_s (src/qp_generator.cpp:226-234), i,j in {3,4,5}
+  auto jerk_init = [&]() {
     const R Q33 = (R)36 * T, Q34 = (R)72 * T2, Q35 = (R)120 * T3, Q44 = (R)192 * T3, Q45 = (R)360 * T4,
             Q55 = (R)720 * T5;
     // lane 0 of a segment carries the segment's jerk term into the sums
@@ -1084,15 +1157,7 @@ __global__ void __launch_bounds__(64) gtop_eval_wave_kernel(const GtopKernelArgs
     R jc = (R)0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const R p0 = w0[k][0], v0 = w0[k][1], a0 = w0[k][2];
-      const R pT = w1[k][0], vT = w1[k][1], aT = w1[k][2];
-      const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
-      const R V = (vT - v0 - a0 * T) * T;
-      const R A = (aT - a0) * T2;
-      const R c3 = ((R)10 * P - (R)4 * V + (R)0.5 * A) * iT3;
-      const R c4 = ((R)-15 * P + (R)7 * V - A) * iT4;
-      const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) * iT5;
-      q[k][0] = p0; q[k][1] = v0; q[k][2] = (R)0.5 * a0; q[k][3] = c3; q[k][4] = c4; q[k][5] = c5;
+      const R c3 = q[k][3], c4 = q[k][4], c5 = q[k][5];
       const R q3 = Q33 * c3 + Q34 * c4 + Q35 * c5;
       const R q4 = Q34 * c3 + Q44 * c4 + Q45 * c5;
       const R q5 = Q35 * c3 + Q45 * c4 + Q55 * c5;
@@ -1102,34 +1167,40 @@ __global__ void __launch_bounds__(64) gtop_eval_wave_kernel(const GtopKernelArgs
       acc[6 * k + 3] = wj2 * q3; acc[6 * k + 4] = wj2 * q4; acc[6 * k + 5] = wj2 * q5;
     }
     acc[18] = wj * jc;
-  }
+  };
 
   // ---- collision samples (:345-409); sample index = li + j*LPS ----
-  if (do_colli) {
+  if constexpr (COLLI) {
     // Sample times (:353, see gtop_eval_kernel): t_i = 1e-3 + i*dt; segments with T < 0.0301 (where the
     // sample COUNT depends on the accumulated value) replay the reference's addition chain.
-    R ts[SPL];
+    // Every term of a sample carries the factor alpha * wc * dt (cd of :509 times the weights of :373/:417);
+    // a sample past the loop bound of :353 contributes nothing, i.e. has that factor zero.  With T >= 0.0301
+    // all 30 samples are inside the bound, so only the replay path below ever has to clear it.
+    R ts[SPL], aw[SPL];
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) ts[j] = (R)(li + j * LPS) * dt + (R)1e-3;
+    for (int j = 0; j < SPL; ++j) {
+      ts[j] = (R)(li + j * LPS) * dt + (R)1e-3;
+      aw[j] = pen_alpha * wdt;
+    }
     const bool tiny_T = T < (R)0.0301;
     if (__ballot(tiny_T) != 0ull) {   // wave-uniform, rare
       if (tiny_T) {
+        dt = T / (R)30.0;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
           R t = (R)1e-3;
           for (int i = 0; i < li + j * LPS; ++i) t += dt;
           ts[j] = t;
+          aw[j] = (t < T) ? pen_alpha * (wc * dt) : (R)0;
         }
       }
     }
     // stage A: positions, index arithmetic, all corner loads in flight
     R vels[SPL][3];
-    bool lives[SPL];
     SdfTap<R> taps[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
       const R t = ts[j];
-      lives[j] = seg_ok & (t < T);   // the loop condition of :353
       const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
       const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;   // d/dt of the powers
       R pos[3];
@@ -1141,23 +1212,40 @@ __global__ void __launch_bounds__(64) gtop_eval_wave_kernel(const GtopKernelArgs
       }
       taps[j] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
     }
+    GTOP_STAMP(4);   // corner loads issued
+    __builtin_amdgcn_sched_barrier(0);   // every corner load is issued above this line ...
+    // ... and what does not need them runs while they are in flight: the jerk term and the speeds
+    jerk_init();
+    R vns[SPL], ivns[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      const R *vel = vels[j];
+      vns[j] = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;   // :358
+      ivns[j] = quick_rcp(vns[j]);
+    }
+#ifdef GTOP_STAMPS
+    asm volatile("" ::"v"(vns[0]), "v"(ivns[SPL - 1]), "v"(acc[18]), "v"(acc[3]));
+    GTOP_STAMP(5);   // in-flight work done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GTOP_STAMP(6);   // corner loads landed
+#endif
+    __builtin_amdgcn_sched_barrier(0);
     // stage B: trilinear blend, penalty, accumulation
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
       const R t = ts[j];
       const R *vel = vels[j];
       const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-      const R vn = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;   // :358
-      const R ivn = quick_rcp(vn);
+      const R vn = vns[j], ivn = ivns[j];
       R g3[3];
       bool is_out;
       const R dist = sdf_blend(taps[j], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
-      const R e = lives[j] ? penalty_exp((pen_d0 - dist) * pen_inv_r, expk) : (R)0;   // exp(-(d - d0)/r)
-      const R cd = pen_alpha * e;   // :509
-      const R gd = pen_gd * e;      // :514
-      acc[18] += wdt * (cd * vn);   // :373, weighted as in :417-418
-      // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
-      const R f1 = is_out ? (R)0 : (wdt * a.res_inv) * (gd * cd * vn), f2 = wdt * (cd * ivn);
+      const R e = penalty_exp((pen_d0 - dist) * pen_inv_r, expk);   // exp(-(d - d0)/r)
+      const R cdw = aw[j] * e;      // wc*dt * cd, cd of :509 (idle lanes compute on shadow data; never read)
+      const R cv = cdw * vn;
+      acc[18] += cv;                // :373, weighted as in :417-418
+      // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381); gd of :514
+      const R f1 = is_out ? (R)0 : ((pen_gd * a.res_inv) * e) * cv, f2 = cdw * ivn;
       const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -1171,8 +1259,14 @@ __global__ void __launch_bounds__(64) gtop_eval_wave_kernel(const GtopKernelArgs
         ak[5] = gfma(w1k, t5, gfma(w2k, d5, ak[5]));
       }
     }
+  } else {
+    (void)wdt; (void)pen_d0; (void)pen_inv_r; (void)pen_alpha; (void)pen_gd;
+    jerk_init();
   }
-
+#ifdef GTOP_STAMPS
+  asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[11]), "v"(acc[17]), "v"(acc[18]));
+  GTOP_STAMP(7);   // stage B done
+#endif
   // ---- A_s^-T on the lane's 18 accumulators: coefficient space -> [p0,pT,v0,vT,a0,aT] per axis ----
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -1186,40 +1280,33 @@ __global__ void __launch_bounds__(64) gtop_eval_wave_kernel(const GtopKernelArgs
     const R o5 = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
     g[0] = o0; g[1] = ap; g[2] = o2; g[3] = o3; g[4] = o4; g[5] = o5;
   }
-
   // ---- the one LDS round trip: tile[v][lane], then each free variable sums its 2*LPS entries ----
   if (lane < LPS * SPW) {
 #pragma unroll
-    for (int v = 0; v < 18; ++v) tile[v * kStride + lane] = acc[v];   // (idle lanes hold exact zeros: e = wj = 0)
+    for (int v = 0; v < 18; ++v) tile[v * kStride + lane] = acc[v];   // (columns of idle slots are never read)
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
-  __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
-#pragma unroll
-  for (int r = 0; r < (NT * 9 * (SPW / NT - 1) + 63) / 64; ++r) {
-    const int qi = lane + 64 * r;
-    int tq = 0, i = qi;
-    if constexpr (NT == 2) {
-      tq = i >= n;
-      i -= tq * n;
-    }
-    const bool ok = grp_ok & (qi < NT * n) & (b0 + tq < a.B);
-    const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
-    const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
-    // free variable = end of segment wpt-1 (entry 2 der + 1) + start of segment wpt (entry 2 der)  (:425-432)
-    const int rowA = axis * 6 + 2 * der + 1, rowB = axis * 6 + 2 * der;
-    const int sA = tq * m + wpt - 1;
-    const R *colA = tile + (ok ? rowA * kStride + sA * LPS : 0);
-    const R *colB = tile + (ok ? rowB * kStride + (sA + 1) * LPS : 0);
-    const R v = tree_sum<R, LPS>(colA) + tree_sum<R, LPS>(colB);
-    if (ok) a.grad[(size_t)b0 * n + qi] = v + (R)1e-5;
-  }
-  // ---- cost (:417-418): every term is already weighted; wavefront sum on the DPP path ----
+  GTOP_STAMP(8);   // A^-T + tile writes issued
+  // ---- cost (:417-418): every term is already weighted; wavefront sum on the DPP path (no LDS), placed
+  //      between the tile's writes and reads so that it covers the LDS latency ----
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const bool mine = seg_ok & (NT == 1 || tl == t);
     const R total = wave_sum(mine ? acc[18] : (R)0);
     if (grp_ok & (lane == 0) & (b0 + t < a.B)) a.cost[b0 + t] = total + (R)1e-3;
   }
+  GTOP_STAMP(9);   // cost summed and stored
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
+  __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const R v = tree_sum<R, LPS>(tile + offA[r]) + tree_sum<R, LPS>(tile + offB[r]);
+    if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = v + (R)1e-5;
+  }
+  GTOP_STAMP(10);   // gradient stored (issued)
+#ifdef GTOP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GTOP_STAMP(11);   // stores acknowledged
+#endif
 }
 
 }  // namespace
@@ -1240,7 +1327,7 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 
 template <typename R, bool DYN, bool MMA, bool WIDE>
 static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, int grid,
-                             size_t smem /* of the generic body */, hipStream_t stream) {
+                             size_t smem /* of the generic body */, hipStream_t stream, bool wave_ok) {
   void (*kern)(const GtopKernelArgs<R>, const GtopMmaState) = nullptr;
   // the specialised straight-line bodies: one wavefront = one whole trajectory (SPL 3 or 6) or two (SPL 6)
   const int groups = (args.B + args.tpb - 1) / args.tpb;
@@ -1260,9 +1347,13 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
 #define GTOP_WAVE_KERNEL 1
 #endif
   if constexpr (GTOP_WAVE_KERNEL && !MMA && !DYN) {
-    if (one && spl == 3) {   // one wavefront per trajectory: the barrier-free chain
-      hipLaunchKernelGGL((gtop_eval_wave_kernel<R, WIDE, 3, 1>), dim3(grid), dim3(64),
-                         18 * red_stride(3) * sizeof(R), stream, args);
+    if (wave_ok && one && spl == 3) {   // one wavefront per trajectory: the barrier-free chain
+      GtopKernelArgs<R> wa = args;
+      if (wa.step == 1) wa.ws = (R)0;   // :412-415, applied here so that the kernel need not fetch `step`
+      const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
+      hipLaunchKernelGGL((colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false>),
+                         dim3(grid), dim3(64), 18 * red_stride(3) * sizeof(R), stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B,
+                         wa.m, wa.t_stride, wa.nx, wa.ny, wa.nz, wa);
       return hipGetLastError();
     }
   }
@@ -1299,7 +1390,7 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
 
 template <typename R, bool MMA>
 static hipError_t launch_any(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, bool dyn,
-                             int max_blocks, hipStream_t stream) {
+                             int max_blocks, hipStream_t stream, bool wave_ok = true) {
   if (args.B <= 0) return hipSuccess;
   const size_t smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R));
   const int groups = (args.B + args.tpb - 1) / args.tpb;
@@ -1307,17 +1398,17 @@ static hipError_t launch_any(const GtopKernelArgs<R> &args, const GtopMmaState &
   const int grid = vblocks < max_blocks ? vblocks : max_blocks;
   const bool wide = !gtop_field_is_narrow(args.nx, args.ny, args.nz, sizeof(R));
   if (wide)
-    return dyn ? launch_spl<R, true, MMA, true>(args, st, waves, spl, grid, smem, stream)
-               : launch_spl<R, false, MMA, true>(args, st, waves, spl, grid, smem, stream);
-  return dyn ? launch_spl<R, true, MMA, false>(args, st, waves, spl, grid, smem, stream)
-             : launch_spl<R, false, MMA, false>(args, st, waves, spl, grid, smem, stream);
+    return dyn ? launch_spl<R, true, MMA, true>(args, st, waves, spl, grid, smem, stream, wave_ok)
+               : launch_spl<R, false, MMA, true>(args, st, waves, spl, grid, smem, stream, wave_ok);
+  return dyn ? launch_spl<R, true, MMA, false>(args, st, waves, spl, grid, smem, stream, wave_ok)
+             : launch_spl<R, false, MMA, false>(args, st, waves, spl, grid, smem, stream, wave_ok);
 }
 
 template <typename R>
 hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
-                            int max_blocks, hipStream_t stream) {
+                            int max_blocks, hipStream_t stream, bool wave_kernel_ok) {
   const GtopMmaState none{};
-  return launch_any<R, false>(args, none, waves, spl, dyn, max_blocks, stream);
+  return launch_any<R, false>(args, none, waves, spl, dyn, max_blocks, stream, wave_kernel_ok);
 }
 
 // cost/gradient at st.xcur + the MMA update, one launch (fp64; spl 1, 3 or 6)
@@ -1332,8 +1423,8 @@ extern "C" int gtop_debug_read_stamps(unsigned long long *out /*4096*16*/) {
 }
 #endif
 
-template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, int, bool, int, hipStream_t);
-template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, int, bool, int, hipStream_t);
+template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, int, bool, int, hipStream_t, bool);
+template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, int, bool, int, hipStream_t, bool);
 
 // ---------------------------------------------------------------------------
 // fp64 -> fp32 copy of the distance field for the GTOP_F32 path

@@ -150,7 +150,9 @@ def test_optimize_device_api_and_determinism(scene, gtop):
     c1, _ = ctx.eval_device(out[0][0], Df, T)
     torch.cuda.synchronize()
     ctx.set_launch_geometry(0, 0)
-    assert torch.equal(c1, out[0][1])            # min_cost is the cost of the returned x
+    # min_cost is the cost of the returned x (a plain evaluation may run another body than the optimizer's:
+    # summation order only)
+    assert torch.max(torch.abs(c1 - out[0][1]) / out[0][1]).item() <= 1e-12
     assert (c1 <= c0).all() and (c1 < 0.5 * c0).float().mean() > 0.9
 
 
