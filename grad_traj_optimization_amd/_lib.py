@@ -108,6 +108,12 @@ def load_library():
         "gtop_get_cost_curve": (C.c_int, [vp, dp, dp, C.c_int, ip]),
         "gtop_clear_cost_curve": (C.c_int, [vp]),
         "gtop_set_launch_geometry": (C.c_int, [vp, C.c_int, C.c_int]),
+        "gtop_rendezvous_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
+        "gtop_rendezvous_destroy": (C.c_int, [vp]),
+        "gtop_rendezvous_get_slot": (vp, [vp, C.c_int]),
+        "gtop_cost_nlopt_shared": (C.c_double, [C.c_uint, dp, dp, vp]),
+        "gtop_rendezvous_leave": (C.c_int, [vp]),
+        "gtop_rendezvous_stats": (C.c_int, [vp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64)]),
         "gtop_set_optimizer_fusion": (C.c_int, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
@@ -388,3 +394,47 @@ class GtopContext:
 
     def clear_cost_curve(self):
         self._chk(self._L.gtop_clear_cost_curve(self._h))
+
+
+class Rendezvous:
+    """N serial callers sharing one launch (include/gtop.h, gtop_rendezvous_*).  The context's problem must hold
+    the N trajectories (row i = caller i).  Each caller thread uses `cost(i, x)` as its objective and calls
+    `leave(i)` when its optimizer has returned."""
+
+    def __init__(self, ctx, n_slots, m):
+        self._L = load_library()
+        self._ctx = ctx
+        h = C.c_void_p()
+        rc = self._L.gtop_rendezvous_create(C.byref(h), ctx._h, int(n_slots), int(m))
+        if rc != 0:
+            raise GtopError(rc, "gtop_rendezvous_create")
+        self._h = h
+        self.n = 9 * (m - 1)
+        self._slots = [C.c_void_p(self._L.gtop_rendezvous_get_slot(h, i)) for i in range(n_slots)]
+
+    def cost(self, i, x, want_grad=True):
+        x = _f64(x)
+        g = np.empty_like(x) if want_grad else None
+        c = self._L.gtop_cost_nlopt_shared(x.size, _p(x), _p(g) if want_grad else None, self._slots[i])
+        if not np.isfinite(c):
+            raise GtopError(1, "gtop_cost_nlopt_shared: " + self._L.gtop_last_error(self._ctx._h).decode())
+        return c, g
+
+    def leave(self, i):
+        self._L.gtop_rendezvous_leave(self._slots[i])
+
+    def stats(self):
+        n, cb, s = C.c_int64(), C.c_int64(), C.c_double()
+        self._L.gtop_rendezvous_stats(self._h, C.byref(n), C.byref(s), C.byref(cb))
+        return dict(launches=n.value, launch_seconds=s.value, callbacks=cb.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gtop_rendezvous_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

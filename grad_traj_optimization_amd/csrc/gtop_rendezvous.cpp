@@ -1,0 +1,210 @@
+// gtop_rendezvous.cpp — N serial callers, one launch.
+//
+// The reference runs one NLopt instance per problem: optimizer.optimize() calls
+// the cost/gradient callback serially, one trajectory per call
+// (src/grad_traj_optimizer.cpp:137-195, :554-562).  A GPU evaluation of ONE
+// trajectory is launch-bound (~20 us, most of it the launch and the
+// synchronisation), so serial callers only profit if their callbacks share a
+// launch.  This layer lets N host threads — each running its own serial
+// optimizer (NLopt's LD_MMA, or csrc/mma.hpp) on its own trajectory — meet:
+// every thread calls gtop_cost_nlopt_shared (exactly NLopt's nlopt_func shape)
+// with its slot as func_data; the call blocks until all slots still in the
+// game have arrived, the last arriver evaluates the whole batch with ONE
+// gtop_eval_batch on the shared context, and every caller returns with its own
+// cost and gradient.  A caller whose optimizer has stopped leaves
+// (gtop_rendezvous_leave); the others no longer wait for it.
+//
+// Results are those of gtop_eval_batch on the same rows: the rows of a batch are
+// independent, so with the launch geometry the context uses for N trajectories
+// each caller sees, bit for bit, what a batch evaluation gives it.
+//
+// Pure host logic over the public C-ABI (include/gtop.h).  A mutex guards the
+// arrival bookkeeping only (tens of nanoseconds per caller); callers sleep on a
+// generation word (futex; a short poll first when every caller has a core), and
+// copy their results out without any lock: a generation's buffers stay put
+// until every caller has arrived again.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include <linux/futex.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include "gtop.h"
+
+struct gtop_rendezvous_slot {
+  gtop_rendezvous *owner;
+  int index;
+  bool active;       // still taking part
+  bool waiting;      // has arrived for the current generation
+  int64_t calls;     // callbacks served (iter_num of this caller, grad_traj_optimizer.cpp:284)
+  double best;       // running minimum of its costs (:439-447)
+};
+
+struct gtop_rendezvous {
+  gtop_ctx *ctx = nullptr;
+  int n_slots = 0;
+  unsigned n = 0;                 // free variables per trajectory
+  unsigned spin = 0;              // polls of the generation word before sleeping on it
+  std::vector<gtop_rendezvous_slot> slots;
+  std::vector<double> x, cost, grad;   // [n_slots][n], [n_slots], [n_slots][n]
+  std::mutex mu;                  // guards the bookkeeping below only: never held across a launch or a sleep
+  int active = 0, arrived = 0;
+  std::atomic<uint32_t> generation{0};   // waiters sleep on this word (futex)
+  int last_status = GTOP_OK;      // of the generation just evaluated
+  int64_t launches = 0;
+  double launch_seconds = 0.0;
+};
+
+namespace {
+
+// cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container sees the
+// whole host in hardware_concurrency())
+int usable_cores() {
+  cpu_set_t set;
+  int n = 1;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32];
+    long period = 0;
+    if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+      const long q = std::atol(quota) / period;
+      if (q >= 1 && q < n) n = (int)q;
+    }
+    std::fclose(f);
+  }
+  return n < 1 ? 1 : n;
+}
+
+void futex_wait(std::atomic<uint32_t> *w, uint32_t seen) {
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+}
+void futex_wake_all(std::atomic<uint32_t> *w) {
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0);
+}
+
+// Every active slot has arrived and the caller was elected under the lock: all the other callers are blocked
+// on the generation word, so nothing else touches the buffers.  Evaluate, publish, wake everybody.
+void run_generation(gtop_rendezvous *r) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int st = gtop_eval_batch(r->ctx, r->n_slots, r->x.data(), r->cost.data(), r->grad.data());
+  {
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->last_status = st;
+    r->launch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    r->launches++;
+    for (auto &s : r->slots) s.waiting = false;
+    r->arrived = 0;
+  }
+  r->generation.fetch_add(1, std::memory_order_release);
+  futex_wake_all(&r->generation);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gtop_rendezvous_create(gtop_rendezvous **out, gtop_ctx *ctx, int n_slots, int m) {
+  if (!out) return GTOP_ERR_INVALID;
+  *out = nullptr;
+  if (!ctx || n_slots < 1 || m < 2) return GTOP_ERR_INVALID;
+  gtop_rendezvous *r = new (std::nothrow) gtop_rendezvous();
+  if (!r) return GTOP_ERR_INVALID;
+  r->ctx = ctx;
+  r->n_slots = n_slots;
+  r->n = 9u * (unsigned)(m - 1);
+  // with a core per caller a short poll beats a sleep/wake pair (~50 us); with more callers than cores polling
+  // only steals the cores the late arrivers need
+  r->spin = n_slots <= usable_cores() ? 20000u : 0u;
+  r->slots.resize(n_slots);
+  for (int i = 0; i < n_slots; ++i) r->slots[i] = gtop_rendezvous_slot{r, i, true, false, 0, HUGE_VAL};
+  r->active = n_slots;
+  r->x.assign((size_t)n_slots * r->n, 0.0);
+  r->cost.assign(n_slots, 0.0);
+  r->grad.assign((size_t)n_slots * r->n, 0.0);
+  *out = r;
+  return GTOP_OK;
+}
+
+int gtop_rendezvous_destroy(gtop_rendezvous *r) {
+  if (!r) return GTOP_ERR_INVALID;
+  delete r;
+  return GTOP_OK;
+}
+
+gtop_rendezvous_slot *gtop_rendezvous_get_slot(gtop_rendezvous *r, int i) {
+  if (!r || i < 0 || i >= r->n_slots) return nullptr;
+  return &r->slots[i];
+}
+
+double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *func_data) {
+  gtop_rendezvous_slot *s = static_cast<gtop_rendezvous_slot *>(func_data);
+  if (!s || !s->owner || !x) return HUGE_VAL;
+  gtop_rendezvous *r = s->owner;
+  if (n != r->n) return HUGE_VAL;
+  bool leader;
+  uint32_t gen;
+  {
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (!s->active || s->waiting) return HUGE_VAL;   // left already / re-entered from a second thread
+    // (the row is this caller's own; the previous generation's launch has completed, or it could not be here)
+    std::memcpy(&r->x[(size_t)s->index * n], x, n * sizeof(double));
+    s->waiting = true;
+    r->arrived++;
+    gen = r->generation.load(std::memory_order_relaxed);
+    leader = r->arrived == r->active;
+  }
+  if (leader) {
+    run_generation(r);   // the last arriver evaluates for everybody
+  } else {
+    for (unsigned i = 0; i < r->spin && r->generation.load(std::memory_order_acquire) == gen; ++i) __builtin_ia32_pause();
+    while (r->generation.load(std::memory_order_acquire) == gen) futex_wait(&r->generation, gen);
+  }
+  // results of this generation stay put until every active caller — this one included — has arrived again
+  if (r->last_status != GTOP_OK) return HUGE_VAL;
+  const double c = r->cost[s->index];
+  if (grad) std::memcpy(grad, &r->grad[(size_t)s->index * n], n * sizeof(double));
+  s->calls++;
+  if (c < s->best) s->best = c;
+  return c;
+}
+
+int gtop_rendezvous_leave(gtop_rendezvous_slot *s) {
+  if (!s || !s->owner) return GTOP_ERR_INVALID;
+  gtop_rendezvous *r = s->owner;
+  bool leader;
+  {
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (!s->active) return GTOP_OK;
+    s->active = false;          // its row keeps its last x: evaluated along, never read
+    r->active--;
+    leader = r->active > 0 && r->arrived == r->active;   // the others were only waiting for this one
+  }
+  if (leader) run_generation(r);
+  return GTOP_OK;
+}
+
+int gtop_rendezvous_stats(gtop_rendezvous *r, int64_t *launches, double *launch_seconds, int64_t *callbacks) {
+  if (!r) return GTOP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(r->mu);
+  if (launches) *launches = r->launches;
+  if (launch_seconds) *launch_seconds = r->launch_seconds;
+  if (callbacks) {
+    int64_t t = 0;
+    for (const auto &s : r->slots) t += s.calls;
+    *callbacks = t;
+  }
+  return GTOP_OK;
+}
+
+}  // extern "C"

@@ -153,6 +153,36 @@ int gtop_eval_batch(gtop_ctx *ctx, int B, const double *x, double *cost,
  * (:284, :436, :439-447) — read them with gtop_get_stats/gtop_get_cost_curve. */
 double gtop_cost_nlopt(unsigned n, const double *x, double *grad, void *ctx);
 
+/* ---- rendezvous: N serial callers share one launch ------------------- */
+/* The reference runs one NLopt instance per problem and each calls the callback
+ * serially (src/grad_traj_optimizer.cpp:137-195, :554-562).  One trajectory per
+ * launch is launch-bound on a GPU, so this layer lets N host threads — each
+ * running its own serial optimizer on its own trajectory — meet in ONE
+ * gtop_eval_batch of the shared context:
+ *   gtop_set_problem(ctx, N, m, ...)           the N problems, row i = caller i
+ *   gtop_rendezvous_create(&r, ctx, N, m)
+ *   thread i:  nlopt_set_min_objective(opt_i, gtop_cost_nlopt_shared,
+ *                                      gtop_rendezvous_get_slot(r, i));
+ *              nlopt_optimize(opt_i, ...);  gtop_rendezvous_leave(slot_i);
+ * gtop_cost_nlopt_shared has exactly NLopt's nlopt_func shape.  It blocks until
+ * every slot that has not left has arrived; the last arriver runs the batch;
+ * each caller gets the cost and gradient of its own row — bit for bit what
+ * gtop_eval_batch gives that row.  A caller MUST call gtop_rendezvous_leave
+ * when its optimizer returns, or the others wait for it forever.  Returns
+ * HUGE_VAL on misuse (wrong n, a slot that has left) or when the evaluation
+ * failed (gtop_last_error(ctx)).  The context must not be used by anything
+ * else while callers are inside. */
+typedef struct gtop_rendezvous gtop_rendezvous;
+typedef struct gtop_rendezvous_slot gtop_rendezvous_slot;
+int gtop_rendezvous_create(gtop_rendezvous **out, gtop_ctx *ctx, int n_slots, int m);
+int gtop_rendezvous_destroy(gtop_rendezvous *r);
+gtop_rendezvous_slot *gtop_rendezvous_get_slot(gtop_rendezvous *r, int i);
+double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *slot);
+int gtop_rendezvous_leave(gtop_rendezvous_slot *slot);
+/* launches so far, seconds spent inside them, callbacks served (all slots) */
+int gtop_rendezvous_stats(gtop_rendezvous *r, int64_t *launches, double *launch_seconds,
+                          int64_t *callbacks);
+
 /* Device-resident form: every pointer is a HIP device pointer of `dtype`
  * elements; launches on `hip_stream` (a hipStream_t, NULL = default stream)
  * and returns without synchronising.  Does not touch the problem set by

@@ -33,3 +33,18 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 1024, 16384]:
             ctx.cost_nlopt(b.x[0])
         dt = (time.perf_counter() - t0) / reps
         print(f"B=1: gtop_cost_nlopt {dt * 1e6:.1f} us per call (the nlopt_func-shaped entry, through ctypes)")
+
+# the rendezvous layer: N serial optimizers (C++ threads, csrc/mma.hpp) sharing launches, amortised per callback
+import json
+import subprocess
+demo = os.path.join(os.getcwd(), "grad_traj_optimization_amd", "gtop_rendezvous_demo")
+if os.path.exists(demo):
+    for threads in (16, 64, 256, 1024):
+        out = subprocess.run([demo, str(threads), "6", "30", "3" if threads > 256 else "0"], capture_output=True, text=True)
+        if out.returncode != 0:
+            print(f"rendezvous {threads}: failed {out.stderr[-200:]}")
+            continue
+        r = json.loads(out.stdout)
+        print(f"rendezvous, {threads} threads: {r['shared_us_per_callback']:.2f} us per callback amortised "
+              f"({r['shared_us_per_launch']:.1f} us per shared launch, {r['us_inside_launches_per_launch']:.1f} us of it inside "
+              f"gtop_eval_batch) vs {r['serial_us_per_callback']:.2f} us per callback one after the other; identical = {r['identical']}")
