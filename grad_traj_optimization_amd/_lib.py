@@ -31,6 +31,11 @@ class GtopParams(C.Structure):
     ]
 
 
+class GtopStop(C.Structure):
+    """gtop_stop — evaluation cap + NLopt's ftol_rel / xtol_rel / maxtime."""
+    _fields_ = [("max_evals", C.c_int32), ("ftol_rel", C.c_double), ("xtol_rel", C.c_double), ("maxtime", C.c_double)]
+
+
 # launch/opti_node.launch:3-28 of the reference — the only parameter set whose
 # names match what the ctor reads.
 OPTI_NODE_PARAMS = dict(ws=1.0, wc=5.0, alpha=10.0, r=0.5, d0=0.8,
@@ -103,6 +108,10 @@ def load_library():
         "gtop_default_bounds": (C.c_int, [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_double, dp, dp]),
         "gtop_optimize_batch": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, dp]),
         "gtop_optimize_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]),
+        "gtop_optimize_batch_ex": (C.c_int, [vp, C.c_int, dp, dp, dp, C.POINTER(GtopStop), dp, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32)]),
+        "gtop_optimize_device_ex": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.POINTER(GtopStop), vp,
+                                              vp, vp, vp]),
         "gtop_get_stats": (C.c_int, [vp, C.POINTER(C.c_int64), dp]),
         "gtop_reset_stats": (C.c_int, [vp]),
         "gtop_get_cost_curve": (C.c_int, [vp, dp, dp, C.c_int, ip]),
@@ -354,6 +363,40 @@ class GtopContext:
         cost = np.empty(B)
         self._chk(self._L.gtop_optimize_batch(self._h, B, _p(x), _p(lb), _p(ub), int(max_evals), _p(cost)))
         return x, cost
+
+    def optimize_batch_ex(self, x0, lb, ub, max_evals, ftol_rel=0.0, xtol_rel=0.0, maxtime=0.0):
+        """As optimize_batch, with NLopt's other stop rules; returns (x, cost, nevals, code)."""
+        x = _f64(x0).copy()
+        B = x.shape[0]
+        lb, ub = _f64(lb), _f64(ub)
+        cost = np.empty(B)
+        nev = np.empty(B, dtype=np.int32)
+        code = np.empty(B, dtype=np.int32)
+        stop = GtopStop(int(max_evals), float(ftol_rel), float(xtol_rel), float(maxtime))
+        ip = C.POINTER(C.c_int32)
+        self._chk(self._L.gtop_optimize_batch_ex(self._h, B, _p(x), _p(lb), _p(ub), C.byref(stop), _p(cost),
+                                                 nev.ctypes.data_as(ip), code.ctypes.data_as(ip)))
+        return x, cost, nev, code
+
+    def optimize_device_ex(self, x, Df, T, lb, ub, max_evals, ftol_rel=0.0, xtol_rel=0.0, maxtime=0.0, stream=None):
+        """torch fp64 CUDA tensors; x is overwritten with the best point; returns (x, min_cost, nevals, code)."""
+        import torch
+        B, n = x.shape
+        m = n // 9 + 1
+        stride = m if T.dim() == 2 else 0
+        for t in (x, Df, T, lb, ub):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64
+        min_cost = torch.empty(B, dtype=torch.float64, device=x.device)
+        nev = torch.empty(B, dtype=torch.int32, device=x.device)
+        code = torch.empty(B, dtype=torch.int32, device=x.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        stop = GtopStop(int(max_evals), float(ftol_rel), float(xtol_rel), float(maxtime))
+        self._chk(self._L.gtop_optimize_device_ex(
+            self._h, B, m, C.c_void_p(x.data_ptr()), C.c_void_p(Df.data_ptr()), C.c_void_p(T.data_ptr()), stride,
+            C.c_void_p(lb.data_ptr()), C.c_void_p(ub.data_ptr()), C.byref(stop), C.c_void_p(min_cost.data_ptr()),
+            C.c_void_p(nev.data_ptr()), C.c_void_p(code.data_ptr()), C.c_void_p(stream)))
+        return x, min_cost, nev, code
 
     def optimize_device(self, x, Df, T, lb, ub, max_evals, min_cost=None, stream=None):
         """torch fp64 CUDA tensors; x is overwritten with the best point."""

@@ -55,6 +55,8 @@ struct gtop_ctx {
   double *mma_scal = nullptr;  // 4 x [B]
   int *mma_int = nullptr;      // 2 x [B]
   double *mma_f = nullptr, *mma_g = nullptr, *mma_lb = nullptr, *mma_ub = nullptr;
+  int *mma_res = nullptr;      // nevals | code of gtop_optimize_batch_ex, 2 x [B]
+  size_t cap_mma_res = 0;
   size_t cap_mma_vec = 0, cap_mma_scal = 0, cap_mma_int = 0, cap_mma_f = 0, cap_mma_g = 0, cap_mma_lb = 0,
          cap_mma_ub = 0;
 
@@ -267,7 +269,7 @@ int gtop_destroy(gtop_ctx *c) {
   release_sdf(c);
   void *bufs[] = {c->occ, c->tmp1, c->tmp2, c->rows, c->boxes, c->d_q, c->d_pts,
                   c->d_T, c->d_Df, c->d_x, c->d_cost, c->d_grad,
-                  c->mma_vec, c->mma_scal, c->mma_int, c->mma_f, c->mma_g, c->mma_lb, c->mma_ub};
+                  c->mma_vec, c->mma_scal, c->mma_int, c->mma_f, c->mma_g, c->mma_lb, c->mma_ub, c->mma_res};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -662,14 +664,17 @@ int gtop_edt_query(gtop_ctx *c, int N, const double *pos, const double *time, do
 // Batched optimizer: max_evals rounds of {cost/gradient, MMA update} per trajectory on
 // `stream` — one launch for the whole loop (fusion mode 2), one per round (1), or two
 // per round (0); no host synchronisation inside.
-int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df, const void *d_T,
-                         int time_stride, const void *d_lb, const void *d_ub, int max_evals, void *d_minf,
-                         void *hip_stream) {
+int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df, const void *d_T,
+                            int time_stride, const void *d_lb, const void *d_ub, const gtop_stop *stop, void *d_minf,
+                            int32_t *d_nevals, int32_t *d_code, void *hip_stream) {
   if (!c) return GTOP_ERR_INVALID;
   int rc = check_eval_state(c);
   if (rc) return rc;
-  if (B < 0 || m < 2 || max_evals < 1 || (time_stride != 0 && time_stride != m))
-    return fail(c, GTOP_ERR_INVALID, "optimize_device: need B >= 0, m >= 2, max_evals >= 1, time_stride in {0, m}");
+  if (!stop || stop->max_evals < 1 || stop->ftol_rel < 0 || stop->xtol_rel < 0 || stop->maxtime < 0)
+    return fail(c, GTOP_ERR_INVALID, "optimize: stop rules need max_evals >= 1 and non-negative tolerances / maxtime");
+  const int max_evals = stop->max_evals;
+  if (B < 0 || m < 2 || (time_stride != 0 && time_stride != m))
+    return fail(c, GTOP_ERR_INVALID, "optimize_device: need B >= 0, m >= 2, time_stride in {0, m}");
   if (B == 0) return GTOP_OK;
   if (!d_x || !d_Df || !d_T || !d_lb || !d_ub) return fail(c, GTOP_ERR_INVALID, "optimize_device: NULL buffer");
   if (!c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
@@ -677,8 +682,8 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const size_t n = 9 * (size_t)(m - 1), bn = (size_t)B * n;
   if ((rc = ensure(c, &c->mma_vec, &c->cap_mma_vec, 6 * bn))) return rc;
-  if ((rc = ensure(c, &c->mma_scal, &c->cap_mma_scal, 4 * (size_t)B))) return rc;
-  if ((rc = ensure(c, &c->mma_int, &c->cap_mma_int, 2 * (size_t)B))) return rc;
+  if ((rc = ensure(c, &c->mma_scal, &c->cap_mma_scal, 5 * (size_t)B))) return rc;
+  if ((rc = ensure(c, &c->mma_int, &c->cap_mma_int, 3 * (size_t)B))) return rc;
   if ((rc = ensure(c, &c->mma_f, &c->cap_mma_f, (size_t)B))) return rc;
   if ((rc = ensure(c, &c->mma_g, &c->cap_mma_g, bn))) return rc;
   GtopMmaState st;
@@ -686,8 +691,11 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
   st.dfdx = st.xprevprev + bn; st.sigma = st.dfdx + bn;
   st.lb = static_cast<const double *>(d_lb);
   st.ub = static_cast<const double *>(d_ub);
-  st.rho = c->mma_scal; st.minf = st.rho + B; st.gval = st.minf + B; st.wval = st.gval + B;
-  st.k = c->mma_int; st.state = st.k + B;
+  st.rho = c->mma_scal; st.minf = st.rho + B; st.gval = st.minf + B; st.wval = st.gval + B; st.fprev = st.wval + B;
+  st.k = c->mma_int; st.state = st.k + B; st.nevals = st.state + B;
+  st.ftol_rel = stop->ftol_rel;
+  st.xtol_rel = stop->xtol_rel;
+  st.max_ticks = (long long)(stop->maxtime * 1e8);   // wall_clock64(): 100 MHz
   HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
   int waves, spl, tpb;
   // whole loop in one launch: the unrolled one-trajectory-per-wavefront body wins at every batch
@@ -720,31 +728,51 @@ int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df,
   }
   HIPCHK(c, hipMemcpyAsync(d_x, st.x, bn * sizeof(double), hipMemcpyDeviceToDevice, s));
   if (d_minf) HIPCHK(c, hipMemcpyAsync(d_minf, st.minf, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(c, gtop_launch_mma_finish(st, B, d_code, d_nevals, s));
   return GTOP_OK;
 }
 
-int gtop_optimize_batch(gtop_ctx *c, int B, double *x, const double *lb, const double *ub, int max_evals,
-                        double *min_cost) {
+int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df, const void *d_T,
+                         int time_stride, const void *d_lb, const void *d_ub, int max_evals, void *d_minf,
+                         void *hip_stream) {
+  const gtop_stop stop = {max_evals, 0.0, 0.0, 0.0};
+  return gtop_optimize_device_ex(c, B, m, d_x, d_Df, d_T, time_stride, d_lb, d_ub, &stop, d_minf, nullptr, nullptr,
+                                 hip_stream);
+}
+
+int gtop_optimize_batch_ex(gtop_ctx *c, int B, double *x, const double *lb, const double *ub, const gtop_stop *stop,
+                           double *min_cost, int32_t *nevals, int32_t *code) {
   if (!c) return GTOP_ERR_INVALID;
   if (c->B == 0) return fail(c, GTOP_ERR_STATE, "gtop_set_problem has not been called");
-  if (B < 1 || B > c->B || !x || !lb || !ub || max_evals < 1)
-    return fail(c, GTOP_ERR_INVALID, "optimize_batch: 1 <= B <= problem batch, non-NULL buffers, max_evals >= 1");
+  if (B < 1 || B > c->B || !x || !lb || !ub || !stop)
+    return fail(c, GTOP_ERR_INVALID, "optimize_batch: 1 <= B <= problem batch, non-NULL buffers and stop rules");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = 9 * (size_t)(c->m - 1), bn = (size_t)B * n;
   int rc;
   if ((rc = ensure(c, &c->mma_lb, &c->cap_mma_lb, bn))) return rc;
   if ((rc = ensure(c, &c->mma_ub, &c->cap_mma_ub, bn))) return rc;
+  if ((rc = ensure(c, &c->mma_res, &c->cap_mma_res, 2 * (size_t)B))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_x, x, bn * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->mma_lb, lb, bn * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->mma_ub, ub, bn * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  if ((rc = gtop_optimize_device(c, B, c->m, c->d_x, c->d_Df, c->d_T, c->t_stride, c->mma_lb, c->mma_ub,
-                                 max_evals, c->d_cost, c->stream)))
+  if ((rc = gtop_optimize_device_ex(c, B, c->m, c->d_x, c->d_Df, c->d_T, c->t_stride, c->mma_lb, c->mma_ub, stop,
+                                    c->d_cost, c->mma_res, c->mma_res + B, c->stream)))
     return rc;
   HIPCHK(c, hipMemcpyAsync(x, c->d_x, bn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (min_cost)
     HIPCHK(c, hipMemcpyAsync(min_cost, c->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (nevals)
+    HIPCHK(c, hipMemcpyAsync(nevals, c->mma_res, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (code)
+    HIPCHK(c, hipMemcpyAsync(code, c->mma_res + B, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
+}
+
+int gtop_optimize_batch(gtop_ctx *c, int B, double *x, const double *lb, const double *ub, int max_evals,
+                        double *min_cost) {
+  const gtop_stop stop = {max_evals, 0.0, 0.0, 0.0};
+  return gtop_optimize_batch_ex(c, B, x, lb, ub, &stop, min_cost, nullptr, nullptr);
 }
 
 // grad_traj_optimizer.cpp:151-179

@@ -85,9 +85,11 @@ __device__ __forceinline__ void gtop_mma_update_trajectory(const GtopMmaState &s
   double *x = st.x + o, *xcur = st.xcur + o, *xprev = st.xprev + o, *xprevprev = st.xprevprev + o;
   double *dfdx = st.dfdx + o, *sigma = st.sigma + o;
   const double *lb = st.lb + o, *ub = st.ub + o;
+  const int state = st.state[b];
+  if (state >= 3) return;   // stopped (wavefront-uniform): the trajectory stays as it was left
   double rho = st.rho[b], minf = st.minf[b];
   int k = st.k[b];
-  const int state = st.state[b];
+  const int nevals = st.nevals[b] + 1;   // this evaluation
   bool new_outer;
 
   if (state == 0) {
@@ -109,6 +111,25 @@ __device__ __forceinline__ void gtop_mma_update_trajectory(const GtopMmaState &s
       }
     }
     if (inner_done) {
+      // stop rules, where the host twin has them (mma.hpp:127-137): after the inner loop, on the last
+      // evaluated f against the f the outer iteration started from, and on xcur against xprev
+      int stop = 0;
+      const double fprev = st.fprev[b];
+      if (st.ftol_rel > 0 && fabs(fcur - fprev) < st.ftol_rel * (fabs(fcur) + fabs(fprev)) * 0.5) stop = GTOP_MMA_FTOL_REACHED;
+      if (!stop && st.xtol_rel > 0) {
+        bool all = true;
+        for (int j = lane; j < n; j += 64)
+          all = all && fabs(xcur[j] - xprev[j]) < st.xtol_rel * (fabs(xcur[j]) + fabs(xprev[j])) * 0.5;
+        if (__all(all)) stop = GTOP_MMA_XTOL_REACHED;
+      }
+      if (stop) {
+        if (lane == 0) {
+          st.minf[b] = minf;
+          st.nevals[b] = nevals;
+          st.state[b] = stop;
+        }
+        return;
+      }
       // end of the outer iteration: relax rho, adapt the asymptotes
       rho = fmax(0.1 * rho, 1e-5);
       if (k > 1) {
@@ -150,6 +171,8 @@ __device__ __forceinline__ void gtop_mma_update_trajectory(const GtopMmaState &s
     st.minf[b] = minf;
     st.k[b] = k;
     st.state[b] = 1;
+    st.nevals[b] = nevals;
+    if (new_outer) st.fprev[b] = fcur;
   }
 }
 

@@ -36,10 +36,16 @@ struct GtopKernelArgs {
 struct GtopMmaState {
   double *x, *xcur, *xprev, *xprevprev, *dfdx, *sigma;   // [B][n]
   const double *lb, *ub;                                  // [B][n]
-  double *rho, *minf, *gval, *wval;                       // [B]
-  int *k, *state;                                         // [B]
+  double *rho, *minf, *gval, *wval, *fprev;               // [B]; fprev: f at the start of the outer iteration
+  int *k, *state, *nevals;                                // [B]; state 0 first evaluation pending, 1 running,
+                                                          //      >= 3 stopped with that nlopt_result code
   int iters;                                              // evaluations per launch of the fused kernel
+  // stop rules beside the evaluation count (mma.hpp:35-39; nlopt set_ftol_rel / set_xtol_rel / set_maxtime,
+  // grad_traj_optimizer.cpp:144-148); 0 = off.  max_ticks: wall clock in ticks of the 100 MHz device clock.
+  double ftol_rel, xtol_rel;
+  long long max_ticks;
 };
+enum { GTOP_MMA_FTOL_REACHED = 3, GTOP_MMA_XTOL_REACHED = 4, GTOP_MMA_MAXEVAL_REACHED = 5, GTOP_MMA_MAXTIME_REACHED = 6 };
 // red_rows: rows of the reduction tile (0 = the full 19; the launcher passes what the kernel variant uses)
 size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem, int red_rows = 0);
 
@@ -80,6 +86,8 @@ hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMm
 hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const double *x0, hipStream_t stream);
 hipError_t gtop_launch_mma_update(const GtopMmaState &st, int B, int n, const double *fcur, const double *gcur,
                                   hipStream_t stream);
+// code[b] = nlopt_result-style stop code, nevals[b] = evaluations used (either may be NULL)
+hipError_t gtop_launch_mma_finish(const GtopMmaState &st, int B, int *code, int *nevals, hipStream_t stream);
 
 // ---- setup + post-processing (gtop_setup.hip), fp64 ----
 #define GTOP_TRAJ_STATS 9   // time_sum, length, jerk, mean_v, max_v, mean_a, max_a, acc_cost, n_samples

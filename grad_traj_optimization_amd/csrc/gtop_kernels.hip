@@ -591,6 +591,7 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
   }
   const R wc = a.wc;
   const bool do_colli = !(gabs(wc) < (R)1e-4);  // :346
+  const unsigned long long t_launch = MMA ? wall_clock64() : 0ull;   // for the wall-clock stop of the optimizer loop
 
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blocks b
   // and b+8 share an L2), so give XCD x the x-th contiguous eighth of the
@@ -612,6 +613,30 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
     GTOP_STAMP(0);
     GTOP_STAMP_HWID();
     const int ntraj = ONE ? 1 : min(TPB, a.B - b0);   // trajectories this pass
+    if constexpr (MMA) {
+      // Stop rules (mma.hpp:35-39; the reference's own is set_maxtime, :144-148): a group whose trajectories have
+      // all stopped (ftol/xtol, gtop_mma_update_trajectory) leaves the loop instead of burning the remaining
+      // evaluations; past the wall-clock limit the ones still running stop where they are (after at least one
+      // evaluation).  Decided by one lane and shared through LDS: the branch must be workgroup-uniform.
+      __shared__ int s_stop;
+      if (tid == 0) {
+        int running = 0;
+        for (int tl = 0; tl < ntraj; ++tl)
+          running += __hip_atomic_load(&st.state[b0 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3;
+        int stop = running == 0;
+        if (!stop && st.max_ticks > 0 && pass > 0 && (long long)(wall_clock64() - t_launch) > st.max_ticks) {
+          for (int tl = 0; tl < ntraj; ++tl)
+            if (__hip_atomic_load(&st.state[b0 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3)
+              st.state[b0 + tl] = GTOP_MMA_MAXTIME_REACHED;
+          stop = 1;
+        }
+        s_stop = stop;
+      }
+      __syncthreads();
+      const int stop = s_stop;
+      __syncthreads();   // s_stop is rewritten by the next pass
+      if (stop) break;
+    }
     const int nseg = ntraj * m;             // live virtual segments
     // ---- phase 1: per (segment, axis): coefficients, jerk cost and jerk gradient ----
     // Its 3*m*TPB lanes read their seven inputs (two waypoints' p,v,a and T_s)

@@ -48,12 +48,30 @@ mma_init_kernel(GtopMmaState st, int B, int n, const double *__restrict__ x0) {
     st.minf[b] = 0.0;
     st.gval[b] = 0.0;
     st.wval[b] = 0.0;
+    st.fprev[b] = 0.0;
     st.k[b] = 0;
     st.state[b] = 0;
+    st.nevals[b] = 0;
   }
 }
 
+// what the caller sees of the stop state: nlopt_result-style code (a trajectory still running when the loop ended
+// has used up its evaluations: MAXEVAL_REACHED) and the evaluations it consumed
+__global__ void __launch_bounds__(256)
+mma_finish_kernel(GtopMmaState st, int B, int *__restrict__ code, int *__restrict__ nevals) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (code) code[b] = st.state[b] >= 3 ? st.state[b] : GTOP_MMA_MAXEVAL_REACHED;
+  if (nevals) nevals[b] = st.nevals[b];
+}
+
 }  // namespace
+
+hipError_t gtop_launch_mma_finish(const GtopMmaState &st, int B, int *code, int *nevals, hipStream_t stream) {
+  if (B <= 0 || (!code && !nevals)) return hipSuccess;
+  hipLaunchKernelGGL(mma_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, st, B, code, nevals);
+  return hipGetLastError();
+}
 
 hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const double *x0, hipStream_t stream) {
   if (B <= 0) return hipSuccess;

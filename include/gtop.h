@@ -217,6 +217,31 @@ int gtop_optimize_device(gtop_ctx *ctx, int B, int m, void *d_x,
                          const void *d_lb, const void *d_ub, int max_evals,
                          void *d_min_cost, void *hip_stream);
 
+/* The same with NLopt's other stop rules (nlopt::opt::set_ftol_rel / set_xtol_rel /
+ * set_maxtime; the reference sets maxtime only, src/grad_traj_optimizer.cpp:144-148;
+ * host twin csrc/mma.hpp:35-39, :127-137).  A trajectory stops by itself — inside
+ * the one-launch loop — when, at the end of an outer MMA iteration,
+ *   |f - f_prev| < ftol_rel (|f| + |f_prev|)/2, or
+ *   |x_j - xprev_j| < xtol_rel (|x_j| + |xprev_j|)/2 for every j,
+ * or, after at least one evaluation, when `maxtime` seconds of device wall
+ * clock have passed since the launch (whole-loop-in-one-launch mode only; not
+ * reproducible, as in the reference).  0 switches a rule off.  A stopped
+ * trajectory costs no further evaluations.  nevals[b]: evaluations trajectory b
+ * used; code[b]: 3 FTOL, 4 XTOL, 5 MAXEVAL, 6 MAXTIME (nlopt_result values).
+ * nevals / code may be NULL (device pointers in the _device form). */
+typedef struct {
+  int32_t max_evals;       /* >= 1 */
+  double ftol_rel, xtol_rel;
+  double maxtime;          /* seconds */
+} gtop_stop;
+int gtop_optimize_batch_ex(gtop_ctx *ctx, int B, double *x, const double *lb,
+                           const double *ub, const gtop_stop *stop, double *min_cost,
+                           int32_t *nevals, int32_t *code);
+int gtop_optimize_device_ex(gtop_ctx *ctx, int B, int m, void *d_x, const void *d_Df,
+                            const void *d_T, int time_stride, const void *d_lb,
+                            const void *d_ub, const gtop_stop *stop, void *d_min_cost,
+                            int32_t *d_nevals, int32_t *d_code, void *hip_stream);
+
 /* ---- post-processing ------------------------------ */
 
 /* Batched GradTrajOptimizer::getCoefficient / getCoefficientFromDerivative

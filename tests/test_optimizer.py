@@ -15,8 +15,8 @@ from tests import scenes
 pytestmark = pytest.mark.gpu
 
 
-def mma_serial(f, x0, lb, ub, max_evals):
-    """numpy twin of csrc/mma.hpp::mma_minimize with an evaluation-count stop."""
+def mma_serial(f, x0, lb, ub, max_evals, ftol_rel=0.0, xtol_rel=0.0, full=False):
+    """numpy twin of csrc/mma.hpp::mma_minimize: evaluation-count stop, ftol_rel, xtol_rel (:127-137)."""
     n = x0.size
     sigma = np.where(np.isinf(lb) | np.isinf(ub), 1.0, 0.5 * (ub - lb))
     x = np.clip(x0, lb, ub).copy()
@@ -45,11 +45,14 @@ def mma_serial(f, x0, lb, ub, max_evals):
         w = np.sum(0.5 * dx2 * den)
         return xc, g, w
 
+    code = 5
     while nev < max_evals:
+        fprev = fcur
         k += 1
         if k > 1:
             xprevprev = xprev.copy()
         xprev = xcur.copy()
+        inner_done = False
         while nev < max_evals:
             xcur, gval, wval = step(x, dfdx, sigma, rho, minf)
             fcur, dcur = f(xcur)
@@ -62,11 +65,21 @@ def mma_serial(f, x0, lb, ub, max_evals):
                 break
             if fcur > gval:
                 rho = min(10 * rho, 1.1 * (rho + (fcur - gval) / wval))
+        if not inner_done:
+            break                                            # out of evaluations inside the inner loop
+        if ftol_rel > 0 and abs(fcur - fprev) < ftol_rel * (abs(fcur) + abs(fprev)) * 0.5:
+            code = 3
+            break
+        if xtol_rel > 0 and np.all(np.abs(xcur - xprev) < xtol_rel * (np.abs(xcur) + np.abs(xprev)) * 0.5):
+            code = 4
+            break
         rho = max(0.1 * rho, 1e-5)
         if k > 1:
             dx2 = (xcur - xprev) * (xprev - xprevprev)
             gam = np.where(dx2 < 0, 0.7, np.where(dx2 > 0, 1.2, 1.0))
             sigma = np.clip(sigma * gam, 0.01 * (ub - lb), 10 * (ub - lb))
+    if full:
+        return x, minf, trace, nev, code
     return x, minf, trace
 
 
@@ -208,3 +221,80 @@ def test_two_step_schedule_batched(scene, oracle_mod, gtop):
     assert np.allclose(c2, c_end2, rtol=1e-6) and (c_end2 <= c_start2 + 1e-12).all()
     assert (c_end2 < c_start2).mean() > 0.9
     ctx.set_params()
+
+
+@pytest.mark.parametrize("rule", [dict(ftol_rel=5e-2), dict(xtol_rel=0.2), dict(ftol_rel=2e-2, xtol_rel=0.1)])
+def test_device_stop_rules_follow_the_serial_algorithm(scene, oracle_mod, gtop, rule):
+    """ftol_rel / xtol_rel inside the one-launch loop (mma.hpp:35-39, :127-137; the reference's own rule is
+    set_maxtime, grad_traj_optimizer.cpp:144-148): every trajectory stops at the evaluation the serial twin stops
+    at, with its code and its iterate, and uses fewer evaluations than the cap.  Compared on the jerk term alone
+    (wc = 0: a convex quadratic, on which the two runs cannot drift apart through rounding — with the collision
+    term an accept/reject decision near a tie flips after ~50 evaluations and moves the stop by an evaluation or
+    two); the three launch forms are compared with the full cost."""
+    mp, ctx, sdf = scene
+    B, m, cap = 16, 6, 80
+    b = problem.make_trajectories(B, m, mp, seed=700)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    ctx.set_problem(b.T, b.Df)
+    # (a) full cost: same decisions whatever the launch form (one body pinned: same bits)
+    ctx.set_params()
+    res = {}
+    ctx.set_launch_geometry(0, 3)
+    for mode in (2, 1, 0):               # whole loop in one launch; one launch per iteration; separate update launch
+        ctx.set_optimizer_fusion(mode)
+        res[mode] = ctx.optimize_batch_ex(b.x, lb, ub, cap, **rule)
+    ctx.set_optimizer_fusion(2)
+    ctx.set_launch_geometry(0, 0)
+    for mode in (1, 0):
+        for a, r in zip(res[mode], res[2]):
+            assert np.array_equal(a, r)
+    assert (res[2][3] != 5).sum() >= B // 2 and res[2][2][res[2][3] != 5].max() < cap      # the rules did fire
+    # (b) jerk term alone against the serial twin
+    kw = dict(wc=0.0)
+    ctx.set_params(**kw)
+    try:
+        xs, costs, nev, code = ctx.optimize_batch_ex(b.x, lb, ub, cap, **rule)
+    finally:
+        ctx.set_params()
+    prm = oracle_mod.make_params(**kw)
+    for i in range(B):
+        gen = oracle_mod.generator(b.T[i])
+
+        def f(x, i=i, gen=gen):
+            return oracle_mod.cost_grad(b.T[i], b.Df[i], x, sdf, prm, L=gen["L"], R=gen["R"])
+        x_ref, f_ref, _, nev_ref, code_ref = mma_serial(f, b.x[i], lb[i], ub[i], cap, full=True, **rule)
+        assert (nev[i], code[i]) == (nev_ref, code_ref), (i, nev[i], code[i], nev_ref, code_ref)
+        assert abs(costs[i] - f_ref) <= 1e-4 * abs(f_ref)          # (up to 80 iterations of rounding differences)
+        assert np.max(np.abs(xs[i] - x_ref)) <= 1e-4 * max(1.0, np.max(np.abs(x_ref)))
+    assert (code != 5).sum() >= B - 2 and nev[code != 5].max() < cap
+    # no rule set: the cap is the only stop, as before
+    x0, c0, n0, k0 = ctx.optimize_batch_ex(b.x, lb, ub, 12)
+    x1, c1 = ctx.optimize_batch(b.x, lb, ub, 12)
+    assert np.array_equal(x0, x1) and np.array_equal(c0, c1) and np.all(n0 == 12) and np.all(k0 == 5)
+
+
+def test_device_wall_clock_stop(scene, gtop):
+    """set_maxtime (grad_traj_optimizer.cpp:144-148) inside the one-launch loop: past the limit every trajectory
+    still running stops after the evaluation it is in (code 6) and returns the best point it has; a generous limit
+    changes nothing."""
+    import torch
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(512, 6, mp, seed=701)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    dev = torch.device("cuda:0")
+    Df = torch.tensor(b.Df.reshape(-1, 18), device=dev)
+    T = torch.tensor(b.T, device=dev)
+    lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
+    ctx.set_params()
+    x, c, nev, code = ctx.optimize_device_ex(torch.tensor(b.x, device=dev), Df, T, lbt, ubt, 400, maxtime=20e-6)
+    torch.cuda.synchronize()
+    assert (code == 6).all() and (nev >= 1).all() and (nev < 400).all()
+    ctx.set_launch_geometry(0, 3)
+    chk, _ = ctx.eval_device(x, Df, T)
+    torch.cuda.synchronize()
+    ctx.set_launch_geometry(0, 0)
+    assert torch.max(torch.abs(chk - c) / c).item() <= 1e-12       # min_cost is the cost of the returned point
+    xa, ca, na, ka = ctx.optimize_device_ex(torch.tensor(b.x, device=dev), Df, T, lbt, ubt, 15, maxtime=10.0)
+    xb, cb = ctx.optimize_device(torch.tensor(b.x, device=dev), Df, T, lbt, ubt, 15)
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb) and torch.equal(ca, cb) and (ka == 5).all() and (na == 15).all()
