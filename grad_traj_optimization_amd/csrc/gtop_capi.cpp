@@ -29,6 +29,7 @@ struct gtop_ctx {
   bool have_grid = false;
   double *sdf64 = nullptr;
   float *sdf32 = nullptr;
+  bool sdf32_stale = false;   // the fp32 copy is made on first use after gtop_update_sdf_map (a third of its writes)
   bool own64 = false, own32 = false;
   size_t sdf_cap64 = 0, sdf_cap32 = 0;   // elements, for owned buffers
 
@@ -131,6 +132,7 @@ void release_sdf(gtop_ctx *c) {
   if (c->own32 && c->sdf32) (void)hipFree(c->sdf32);
   c->sdf64 = nullptr;
   c->sdf32 = nullptr;
+  c->sdf32_stale = false;
   c->own64 = c->own32 = false;
   c->sdf_cap64 = c->sdf_cap32 = 0;
 }
@@ -304,6 +306,7 @@ int gtop_set_sdf(gtop_ctx *c, const double *dist_host, int nx, int ny, int nz,
   if ((rc = own_sdf_buffers(c, nvox))) { c->have_grid = false; return rc; }
   HIPCHK(c, hipMemcpyAsync(c->sdf64, dist_host, nvox * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, c->stream));
+  c->sdf32_stale = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 }
@@ -339,6 +342,7 @@ int gtop_init_sdf_map(gtop_ctx *c, const double map_size[3], const double origin
   // sdf_map.cpp:22-23: distance 10000, occupancy 0
   HIPCHK(c, gtop_launch_esdf_reset(c->occ, c->sdf64, nvox, c->stream));
   HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, c->stream));
+  c->sdf32_stale = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 }
@@ -363,9 +367,12 @@ int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
     if ((rc = ensure(c, &c->d_pts, &c->pts_cap, (size_t)npts * 3))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, (size_t)npts * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
-  HIPCHK(c, gtop_launch_esdf_reset(c->occ, c->sdf64, nvox, c->stream));            // resetBuffer
+  // resetBuffer (sdf_map.cpp:26-53): the occupancy; the distances need no reset of their own, the x sweep
+  // writes every voxel (10000 where the line holds no obstacle, as the reset would have left it)
+  HIPCHK(c, gtop_launch_esdf_reset(c->occ, nullptr, nvox, c->stream));
   HIPCHK(c, gtop_launch_esdf_mark(g, c->d_pts, npts, c->occ, c->stream));         // setOccupancy
-  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, c->sdf32, c->stream));   // updateESDF3d
+  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, nullptr, c->stream));   // updateESDF3d
+  c->sdf32_stale = true;   // converted by the first fp32 evaluation that needs it
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 }
@@ -495,6 +502,11 @@ int gtop_eval_device(gtop_ctx *c, int dtype, int B, int m, const void *d_x, cons
     return launch_eval<double>(c, c->sdf64, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
   } else if (dtype == GTOP_F32) {
     if (!c->sdf32) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
+    if (c->sdf32_stale) {   // (gtop_update_sdf_map has synchronised: the fp64 field is complete)
+      const GtopGrid &g = c->grid;
+      HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, (size_t)g.nx * g.ny * g.nz, s));
+      c->sdf32_stale = false;
+    }
     return launch_eval<float>(c, c->sdf32, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
   }
   return fail(c, GTOP_ERR_INVALID, "bad dtype");

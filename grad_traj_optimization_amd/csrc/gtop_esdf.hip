@@ -21,16 +21,23 @@
 //             ballots/popcounts).  A voxel walks that list outward from its own y,
 //             four candidates per round trip, with the exact cut-off d^2 >= best;
 //             obstacle-free stretches cost nothing;
-//   x sweep : outward scan v = q, q±1, q±2, ... with the same cut-off (in(v) >= 0),
-//             neighbouring lanes on neighbouring z so every step is a coalesced
-//             row, 4 steps per round trip — the scan is latency-bound, not
-//             bandwidth-bound;
+//   x sweep : outward scan v = q-1, q+1, q-2, ... with the same cut-off (in(v) >= 0);
 //             it also applies the final res*sqrt(.) (exactly rounded fp64, as the
-//             reference's) and writes the fp32 copy used by the GTOP_F32 path.
-// Result: bit-identical to the CPU restatement and to scipy's exact EDT
-// (tests), HBM/latency-bound integer work, no scratch workspace.  (An LDS-tiled
-// variant of the y/x scans was measured 4-6x SLOWER: 3 200 long-running
-// wavefronts instead of 125 000 short ones; profiles/r1/esdf_kernels.txt.)
+//             reference's).  The fp32 copy used by the GTOP_F32 path is made by the
+//             caller on first use (a third of the sweep's writes).
+// What bounds the scans, and what this file does about it (measured, profiles/r2/esdf_kernels.txt):
+//   * the texture-address unit takes 16 cycles per wave64 load whatever its width, so a lane owns 4 voxels
+//     adjacent in z and every load is 16 bytes (y sweep 46 -> 22 us at 200^3);
+//   * the x sweep re-read every row ~40 times (once per slab within reach): a lane now owns 4 consecutive
+//     slabs as well and one outward pass serves all four (106 -> 65 us), and the yz plane is partitioned over
+//     the 8 XCDs so that those re-reads hit one L2 instead of crossing the fabric (400^3: 1.44 -> 0.96 ms
+//     before the blocking; 0.45 ms with it);
+//   * what is left in the x sweep is its integer min-plus arithmetic (3 instructions per two candidates).
+// Result: bit-identical to the CPU restatement and to scipy's exact EDT (tests), no scratch workspace.
+// Rejected with measurements: an LDS-tiled variant of the scans (4-6x slower, round 1); the reference's own
+// lower-envelope algorithm with one lane per line and the stack in LDS (155 us for the x sweep at 200^3, 2.8 ms
+// at 400^3: a line's pops diverge across the 64 lanes and 4 B x line length of LDS per lane leaves one
+// wavefront per CU at 400^3).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,7 +54,7 @@ esdf_reset_kernel(uint8_t *__restrict__ occ, double *__restrict__ dist, size_t n
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < nvox; i += stride) {
     occ[i] = 0;
-    dist[i] = 10000.0;   // sdf_map.cpp:22, :51
+    if (dist) dist[i] = 10000.0;   // sdf_map.cpp:22, :51
   }
 }
 
@@ -139,100 +146,196 @@ esdf_rows_kernel(const GtopGrid g, const uint8_t *__restrict__ colany, int *__re
   }
 }
 
+// The y and x scans below are bound by the texture-address unit: a wave64 load instruction occupies it for 16
+// cycles whether each lane fetches 4 bytes or 16 (measured: the one-voxel-per-lane x scan at 200^3 ran 20 000
+// loads per CU in 122 us = 16 cycles each).  So a lane owns V = 4 voxels adjacent in z (the fastest axis) and every
+// load is a 16-byte one: the same rows in a quarter of the instructions.  The four voxels share the scan's radius
+// (the widest of theirs; the extra candidates a voxel sees cannot win).  V = 1 serves grids whose nz is not a
+// multiple of 4.
+template <int V> struct IntV;
+template <> struct IntV<1> { int v[1]; };
+template <> struct __attribute__((aligned(16))) IntV<4> { int v[4]; };
+
+template <int V>
+__device__ __forceinline__ IntV<V> load_v(const int *p) { return *reinterpret_cast<const IntV<V> *>(p); }
+
 // y sweep (sdf_map.cpp:328-346): out(x,y,z) = min over candidate columns v of (y-v)^2 + in(x,v,z).
+// 32-bit index arithmetic throughout (nvox < 2^31; ny, nz < 2^15 so that v*nz is a 24-bit product).
+template <int V>
 __global__ void __launch_bounds__(256)
 esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ fout, const int *__restrict__ cols,
               const int *__restrict__ rank, const int *__restrict__ cnt) {
   constexpr int U = 4;   // candidates per round trip and side
-  const size_t nvox = (size_t)g.nx * g.ny * g.nz;
-  const size_t nyz = (size_t)g.ny * g.nz;
+  const int nyz = g.ny * g.nz;
   const int ny = g.ny, nz = g.nz;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i / nyz);
-    const size_t r = i - (size_t)x * nyz;
-    const int q = (int)(r / nz);
-    const int *line = fin + (i - (size_t)q * nz);   // (x, 0, z)
-    const int *cx = cols + (size_t)x * ny;
-    const int c = cnt[x];
-    int best = fin[i];
-    const int k0 = rank[(size_t)x * ny + q];        // first candidate at or above q
-    // below q: candidates k0-1, k0-2, ... (descending y, ascending distance)
-    for (int k = k0 - 1; k >= 0; k -= U) {
-      const int d0 = q - cx[k];
-      if (d0 * d0 >= best) break;   // in(v) >= 0: nothing farther can win
-      int v[U], f[U];
+  // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: slab x (whose voxels only read
+  // slab x) goes to XCD x mod 8, so a slab is fetched into ONE L2 instead of all eight.
+  // grid = 8 * ceil(nx/8) * bps workgroups, bps = ceil(nyz/V/256).
+  const int bps = (nyz / V + 255) >> 8;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int x = xcd + 8 * (j / bps);
+  const int r = ((j % bps) * 256 + (int)threadIdx.x) * V;
+  if (x >= g.nx || r >= nyz) return;
+  const int i = x * nyz + r;
+  const int q = r / nz;                   // (nz % V == 0: the V voxels share q)
+  const int *line = fin + (i - q * nz);   // (x, 0, z)
+  const int *cx = cols + x * ny;
+  const int c = cnt[x];
+  IntV<V> best = load_v<V>(fin + i);
+  int worst = best.v[0];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = (k - u >= 0) ? cx[k - u] : -1;
+  for (int e = 1; e < V; ++e) worst = max(worst, best.v[e]);
+  const int k0 = rank[x * ny + q];        // first candidate at or above q
+  // below q: candidates k0-1, k0-2, ... (descending y, ascending distance).  Indices are clamped to the
+  // list's first entry instead of masked: a re-read candidate cannot beat itself.
+  for (int k = k0 - 1; k >= 0; k -= U) {
+    const int d0 = q - cx[k];
+    if (__mul24(d0, d0) >= worst) break;   // in(v) >= 0: nothing farther can win
+    int v[U];
+    IntV<V> f[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = (v[u] >= 0) ? line[(size_t)v[u] * nz] : kInf;
+    for (int u = 0; u < U; ++u) v[u] = cx[max(k - u, 0)];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int d = q - v[u];
-        const int cand = (v[u] >= 0) ? d * d + f[u] : kInf;   // d <= 2^15, f <= kInf: below 2^31
-        best = cand < best ? cand : best;
-      }
+    for (int u = 0; u < U; ++u) f[u] = load_v<V>(line + __mul24(v[u], nz));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int d = q - v[u], d2 = __mul24(d, d);
+#pragma unroll
+      for (int e = 0; e < V; ++e) best.v[e] = min(best.v[e], d2 + f[u].v[e]);   // d <= 2^15, f <= kInf: below 2^31
     }
-    // above q (the voxel's own column, if it is a candidate, is `best` already)
-    for (int k = k0 + ((k0 < c && cx[k0] == q) ? 1 : 0); k < c; k += U) {
-      const int d0 = cx[k] - q;
-      if (d0 * d0 >= best) break;
-      int v[U], f[U];
+    worst = best.v[0];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = (k + u < c) ? cx[k + u] : -1;
-#pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = (v[u] >= 0) ? line[(size_t)v[u] * nz] : kInf;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int d = v[u] - q;
-        const int cand = (v[u] >= 0) ? d * d + f[u] : kInf;
-        best = cand < best ? cand : best;
-      }
-    }
-    fout[i] = best > kInf ? kInf : best;
+    for (int e = 1; e < V; ++e) worst = max(worst, best.v[e]);
   }
+  // above q (the voxel's own column, if it is a candidate, is `best` already)
+  for (int k = k0 + ((k0 < c && cx[k0] == q) ? 1 : 0); k < c; k += U) {
+    const int d0 = cx[k] - q;
+    if (__mul24(d0, d0) >= worst) break;
+    int v[U];
+    IntV<V> f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = cx[min(k + u, c - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = load_v<V>(line + __mul24(v[u], nz));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int d = v[u] - q, d2 = __mul24(d, d);
+#pragma unroll
+      for (int e = 0; e < V; ++e) best.v[e] = min(best.v[e], d2 + f[u].v[e]);
+    }
+    worst = best.v[0];
+#pragma unroll
+    for (int e = 1; e < V; ++e) worst = max(worst, best.v[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) best.v[e] = best.v[e] > kInf ? kInf : best.v[e];
+  *reinterpret_cast<IntV<V> *>(fout + i) = best;
 }
 
-// x sweep (sdf_map.cpp:348-364): one lane per voxel, lanes along z.
-// out(q) = min_v ((q-v)^2 + in(v)), scanning outward; then dist = min(res*sqrt(out), previous).
+// x sweep (sdf_map.cpp:348-364): out(q) = min_v ((q-v)^2 + in(v)), scanning outward; then
+// dist = min(res*sqrt(out), previous).  A lane owns a block of V voxels along z times kXB = 4 consecutive slabs
+// along x: the rows the four slabs' scans need overlap almost entirely, so one pass outward from the block
+// (rows q0-d and q0+3+d, distance d+e resp. d+3-e to the block's e-th slab) serves all of them — a quarter of the
+// loads of four separate scans, which is what bounded this kernel (L2 bandwidth: every row was re-read by the
+// ~2 x 20 slabs around it).  Element indices advance by +-nyz per step and are CLAMPED to the line's ends instead
+// of masked: past an end the lane re-reads the end row with a larger d, an over-estimate of a candidate it has
+// already seen, which can never win: exact.  The scan stops when (d+1)^2 >= the worst of the block's minima.
+#ifndef GTOP_ESDF_XB
+#define GTOP_ESDF_XB 4
+#endif
+constexpr int kXB = GTOP_ESDF_XB;
+
+template <int V>
 __global__ void __launch_bounds__(256)
 esdf_x_kernel(const GtopGrid g, const int *__restrict__ fin, double *__restrict__ dist, float *__restrict__ dist32) {
-  constexpr int kScanBatch = 4;   // steps per round trip (4 beats 8 and 16 at 400^3; profiles/r1/esdf_kernels.txt)
-  const size_t nvox = (size_t)g.nx * g.ny * g.nz;
-  const size_t nyz = (size_t)g.ny * g.nz;
+  constexpr int kScanBatch = 4;   // steps per round trip
+  const int nyz = g.ny * g.nz;
   const int n = g.nx;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (size_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i / nyz);
-    const int *line = fin + (i - (size_t)q * nyz);
-    int best = line[(size_t)q * nyz];
-    const int reach = q > n - 1 - q ? q : n - 1 - q;
-    // The loads of a batch are independent and issue together; entries past the exact
-    // cut-off d^2 >= best cannot win (in(v) >= 0), so reading a few of them changes nothing.
-    for (int d0 = 1; d0 <= reach; d0 += kScanBatch) {
-      if (d0 * d0 >= best) break;
-      int lo[kScanBatch], hi[kScanBatch];
+  // XCD-aware order: the yz plane is cut in 8 parts and XCD c scans part c of every slab block, block after block —
+  // the rows a lane reads are then shared, in one L2, with the lanes of the neighbouring slab blocks that run at
+  // the same time (dealt linearly, every XCD walked every slab: 1.44 ms -> 0.96 ms at 400^3 with this order).
+  // grid = 8 * ceil(n/kXB) * bpp workgroups, bpp = workgroups per part = ceil(ceil(nyz/V/8)/256).
+  const int nl = nyz / V;
+  const int bpp = (((nl + 7) >> 3) + 255) >> 8, part = bpp << 8;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int q0 = (j / bpp) * kXB;
+  const int fl = xcd * part + (j % bpp) * 256 + (int)threadIdx.x;
+  if (fl >= nl || fl >= (xcd + 1) * part) return;
+  const int first = fl * V;                 // the line (y,z) = its voxel in slab 0
+  const int last = first + (n - 1) * nyz;   // the line's end voxels: first, last
+  // the block's own rows (slabs past the end of the line shadow the last one; they are not stored)
+  int row[kXB];
+  IntV<V> best[kXB];
 #pragma unroll
-      for (int u = 0; u < kScanBatch; ++u) {
-        const int d = d0 + u;
-        lo[u] = (q - d >= 0) ? line[(size_t)(q - d) * nyz] : kInf;
-        hi[u] = (q + d < n) ? line[(size_t)(q + d) * nyz] : kInf;
-      }
+  for (int e = 0; e < kXB; ++e) {
+    row[e] = first + min(q0 + e, n - 1) * nyz;
+    best[e] = load_v<V>(fin + row[e]);
+  }
+  {
+    IntV<V> own[kXB];
 #pragma unroll
-      for (int u = 0; u < kScanBatch; ++u) {
-        const int d = d0 + u;
-        const int f = lo[u] < hi[u] ? lo[u] : hi[u];
-        const int c = d * d + f;   // < 2^31: d <= 2^15, f <= kInf
-        best = c < best ? c : best;
+    for (int e = 0; e < kXB; ++e) own[e] = best[e];
+#pragma unroll
+    for (int e = 0; e < kXB; ++e)
+#pragma unroll
+      for (int o = 0; o < kXB; ++o)
+        if (o != e)
+#pragma unroll
+          for (int v = 0; v < V; ++v) best[e].v[v] = min(best[e].v[v], (e - o) * (e - o) + own[o].v[v]);
+  }
+  auto worst_of = [&]() {
+    int w = 0;
+#pragma unroll
+    for (int e = 0; e < kXB; ++e)
+#pragma unroll
+      for (int v = 0; v < V; ++v) w = max(w, best[e].v[v]);
+    return w;
+  };
+  int worst = worst_of();
+  const int reach = max(max(q0, n - kXB - q0), 0);
+  int lo = row[0], hi = row[kXB - 1], d = 0;
+  // The loads of a batch are independent and issue together; entries past the exact
+  // cut-off cannot win (in(v) >= 0), so reading a few of them changes nothing.
+  while (d < reach) {
+    if (__mul24(d + 1, d + 1) >= worst) break;
+    IntV<V> flo[kScanBatch], fhi[kScanBatch];
+#pragma unroll
+    for (int u = 0; u < kScanBatch; ++u) {
+      lo = max(lo - nyz, first);
+      hi = min(hi + nyz, last);
+      flo[u] = load_v<V>(fin + lo);
+      fhi[u] = load_v<V>(fin + hi);
+    }
+#pragma unroll
+    for (int u = 0; u < kScanBatch; ++u) {
+      ++d;
+#pragma unroll
+      for (int e = 0; e < kXB; ++e) {
+        const int dl = d + e, dr = d + (kXB - 1 - e);
+        const int dl2 = __mul24(dl, dl), dr2 = __mul24(dr, dr);   // (24-bit multiplies are full rate, 32-bit ones a
+                                                                  // quarter; d <= 2^15, f <= kInf: sums below 2^31)
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          best[e].v[v] = min(best[e].v[v], min(dl2 + flo[u].v[v], dr2 + fhi[u].v[v]));
       }
     }
-    // sdf_map.cpp:355-361: min(res*sqrt(val), previous) with previous = 10000 after the
-    // reset; a line without obstacles carries DBL_MAX there, i.e. keeps the 10000
-    double dv = 10000.0;
-    if (best < kInf) {
-      const double e = g.res * sqrt((double)best);
-      dv = e < dv ? e : dv;
+    worst = worst_of();
+  }
+  // sdf_map.cpp:355-361: min(res*sqrt(val), previous) with previous = 10000 after the
+  // reset; a line without obstacles carries DBL_MAX there, i.e. keeps the 10000
+#pragma unroll
+  for (int e = 0; e < kXB; ++e) {
+    if (q0 + e >= n) break;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      double dv = 10000.0;
+      if (best[e].v[v] < kInf) {
+        const double r = g.res * sqrt((double)best[e].v[v]);
+        dv = r < dv ? r : dv;
+      }
+      dist[row[e] + v] = dv;
+      if (dist32) dist32[row[e] + v] = (float)dv;   // (wave-uniform; the caller may make the fp32 copy later)
     }
-    dist[i] = dv;
-    dist32[i] = (float)dv;
   }
 }
 
@@ -261,7 +364,7 @@ size_t gtop_esdf_rows_ints(const GtopGrid &g) {
 
 hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,
                                   double *dist, float *dist32, hipStream_t stream) {
-  const size_t ncol = (size_t)g.nx * g.ny, nvox = ncol * g.nz;
+  const size_t ncol = (size_t)g.nx * g.ny;
   int *cols = rows, *rank = rows + ncol, *cnt = rows + 2 * ncol;
   uint8_t *colany = reinterpret_cast<uint8_t *>(rows + 2 * ncol + g.nx);
   const unsigned zblocks = (unsigned)((ncol + 3) / 4 < 65536 ? (ncol + 3) / 4 : 65536);
@@ -272,11 +375,25 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
                      (const uint8_t *)colany, cols, rank, cnt);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const unsigned vblocks = (unsigned)((nvox + 255) / 256 < (1u << 20) ? (nvox + 255) / 256 : (1u << 20));
-  hipLaunchKernelGGL(esdf_y_kernel, dim3(vblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2,
-                     (const int *)cols, (const int *)rank, (const int *)cnt);
+  const int nyz = g.ny * g.nz;
+#ifndef GTOP_ESDF_VEC
+#define GTOP_ESDF_VEC 4
+#endif
+  const int V = (GTOP_ESDF_VEC == 4 && g.nz % 4 == 0) ? 4 : 1;   // voxels per lane (16-byte loads need nz % 4 == 0)
+  const int nl = nyz / V;
+  const unsigned yblocks = 8u * (unsigned)((g.nx + 7) / 8) * (unsigned)((nl + 255) / 256);
+  const unsigned xblocks = 8u * (unsigned)((g.nx + kXB - 1) / kXB) * (unsigned)((((nl + 7) >> 3) + 255) >> 8);
+  if (V == 4)
+    hipLaunchKernelGGL(esdf_y_kernel<4>, dim3(yblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2,
+                       (const int *)cols, (const int *)rank, (const int *)cnt);
+  else
+    hipLaunchKernelGGL(esdf_y_kernel<1>, dim3(yblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2,
+                       (const int *)cols, (const int *)rank, (const int *)cnt);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(esdf_x_kernel, dim3(vblocks), dim3(256), 0, stream, g, (const int *)tmp2, dist, dist32);
+  if (V == 4)
+    hipLaunchKernelGGL(esdf_x_kernel<4>, dim3(xblocks), dim3(256), 0, stream, g, (const int *)tmp2, dist, dist32);
+  else
+    hipLaunchKernelGGL(esdf_x_kernel<1>, dim3(xblocks), dim3(256), 0, stream, g, (const int *)tmp2, dist, dist32);
   return hipGetLastError();
 }
