@@ -105,6 +105,10 @@ def load_library():
         "gtop_set_moving_boxes": (C.c_int, [vp, C.c_int, dp, dp, dp]),
         "gtop_edt_query_device": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp]),
         "gtop_edt_query": (C.c_int, [vp, C.c_int, dp, dp, dp, dp]),
+        "gtop_edt_coarse_query_device": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+        "gtop_edt_coarse_query": (C.c_int, [vp, C.c_int, dp, dp, dp]),
+        "gtop_sample_trajectories_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp, C.c_int, vp]),
+        "gtop_trajectory_samples": (C.c_int, [vp, C.c_int, dp, C.c_double, dp, dp, dp, C.c_int]),
         "gtop_default_bounds": (C.c_int, [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_double, dp, dp]),
         "gtop_optimize_batch": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, dp]),
         "gtop_optimize_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp]),
@@ -310,6 +314,17 @@ class GtopContext:
         self._chk(self._L.gtop_trajectory_stats(self._h, B, _p(x), float(dt_sample), _p(coeff), _p(stats)))
         return coeff, stats
 
+    def trajectory_samples(self, x, dt_sample=0.01, max_samples=4096):
+        """PolynomialTraj::getTraj for the context's problem at free variables x:
+        (stats (B, 9), samples (B, max_samples, 3)); trajectory b has stats[b, 8] points."""
+        x = _f64(x)
+        B = x.shape[0]
+        stats = np.empty((B, len(self.TRAJ_STATS)))
+        samples = np.zeros((B, int(max_samples), 3))
+        self._chk(self._L.gtop_trajectory_samples(self._h, B, _p(x), float(dt_sample), None, _p(stats), _p(samples),
+                                                  int(max_samples)))
+        return stats, samples
+
     # -- static field + moving boxes (EDTEnvironment) --
     def set_moving_boxes(self, p0, vel, scale):
         """Boxes {p0, vel, scale}, each (nbox, 3): centre p0 + vel*t, extent +-scale/2."""
@@ -325,6 +340,14 @@ class GtopContext:
         grad = np.empty((pos.shape[0], 3))
         self._chk(self._L.gtop_edt_query(self._h, pos.shape[0], _p(pos), _p(time), _p(dist), _p(grad)))
         return dist, grad
+
+    def edt_coarse_query(self, pos, time):
+        """EDTEnvironment::evaluateCoarseEDT: dist (N,) at pos (N, 3), time (N,); time < 0 = static field only."""
+        pos = _f64(pos).reshape(-1, 3)
+        time = _f64(np.broadcast_to(time, (pos.shape[0],)))
+        dist = np.empty(pos.shape[0])
+        self._chk(self._L.gtop_edt_coarse_query(self._h, pos.shape[0], _p(pos), _p(time), _p(dist)))
+        return dist
 
     def edt_query_device(self, pos, time, stream=None):
         """torch fp64 CUDA tensors pos (N, 3), time (N,) -> dist (N,), grad (N, 3); asynchronous."""

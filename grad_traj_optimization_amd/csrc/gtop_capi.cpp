@@ -584,24 +584,36 @@ int gtop_coefficients_device(gtop_ctx *c, int B, int m, const void *d_x, const v
   return GTOP_OK;
 }
 
-int gtop_eval_trajectories_device(gtop_ctx *c, int B, int m, const void *d_coeff, const void *d_T, int time_stride,
-                                  double dt_sample, void *d_stats, void *hip_stream) {
+int gtop_sample_trajectories_device(gtop_ctx *c, int B, int m, const void *d_coeff, const void *d_T, int time_stride,
+                                    double dt_sample, void *d_stats, void *d_samples, int max_samples,
+                                    void *hip_stream) {
   if (!c) return GTOP_ERR_INVALID;
-  if (B < 0 || m < 1 || !(dt_sample > 0.0) || (time_stride != 0 && time_stride != m))
+  if (B < 0 || m < 1 || !(dt_sample > 0.0) || (time_stride != 0 && time_stride != m) || max_samples < 0)
     return fail(c, GTOP_ERR_INVALID, "eval_trajectories: need B >= 0, m >= 1, dt_sample > 0, time_stride in {0, m}");
   if (B == 0) return GTOP_OK;
   if (!d_coeff || !d_T || !d_stats) return fail(c, GTOP_ERR_INVALID, "eval_trajectories: NULL buffer");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, gtop_launch_eval_trajectories(B, m, static_cast<const double *>(d_coeff), static_cast<const double *>(d_T),
                                           time_stride, dt_sample, static_cast<double *>(d_stats),
+                                          max_samples > 0 ? static_cast<double *>(d_samples) : nullptr, max_samples,
                                           static_cast<hipStream_t>(hip_stream)));
   return GTOP_OK;
 }
 
+int gtop_eval_trajectories_device(gtop_ctx *c, int B, int m, const void *d_coeff, const void *d_T, int time_stride,
+                                  double dt_sample, void *d_stats, void *hip_stream) {
+  return gtop_sample_trajectories_device(c, B, m, d_coeff, d_T, time_stride, dt_sample, d_stats, nullptr, 0, hip_stream);
+}
+
 int gtop_trajectory_stats(gtop_ctx *c, int B, const double *x, double dt_sample, double *coeff, double *stats) {
+  return gtop_trajectory_samples(c, B, x, dt_sample, coeff, stats, nullptr, 0);
+}
+
+int gtop_trajectory_samples(gtop_ctx *c, int B, const double *x, double dt_sample, double *coeff, double *stats,
+                            double *samples, int max_samples) {
   if (!c) return GTOP_ERR_INVALID;
   if (c->B == 0) return fail(c, GTOP_ERR_STATE, "gtop_set_problem / gtop_set_paths has not been called");
-  if (B < 1 || B > c->B || !x || (!coeff && !stats))
+  if (B < 1 || B > c->B || !x || (!coeff && !stats && !samples) || max_samples < 0 || (samples && max_samples == 0))
     return fail(c, GTOP_ERR_INVALID, "trajectory_stats: 1 <= B <= problem batch, x and an output required");
   HIPCHK(c, hipSetDevice(c->device));
   const int m = c->m;
@@ -612,11 +624,17 @@ int gtop_trajectory_stats(gtop_ctx *c, int B, const double *x, double dt_sample,
   HIPCHK(c, hipMemcpyAsync(c->d_x, x, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
   if ((rc = gtop_coefficients_device(c, B, m, c->d_x, c->d_Df, c->d_T, c->t_stride, c->mma_g, c->stream))) return rc;
   if (coeff) HIPCHK(c, hipMemcpyAsync(coeff, c->mma_g, ncoef * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  if (stats) {
-    if ((rc = gtop_eval_trajectories_device(c, B, m, c->mma_g, c->d_T, c->t_stride, dt_sample, c->mma_f, c->stream)))
+  if (stats || samples) {
+    const size_t ns = samples ? (size_t)B * max_samples * 3 : 0;
+    if (ns && (rc = ensure(c, &c->d_q, &c->cap_q, ns))) return rc;   // (the query staging buffer doubles as sample scratch)
+    if (ns) HIPCHK(c, hipMemsetAsync(c->d_q, 0, ns * sizeof(double), c->stream));   // rows past a trajectory's count read 0
+    if ((rc = gtop_sample_trajectories_device(c, B, m, c->mma_g, c->d_T, c->t_stride, dt_sample, c->mma_f,
+                                              samples ? c->d_q : nullptr, samples ? max_samples : 0, c->stream)))
       return rc;
-    HIPCHK(c, hipMemcpyAsync(stats, c->mma_f, (size_t)B * GTOP_TRAJ_STATS * sizeof(double), hipMemcpyDeviceToHost,
-                             c->stream));
+    if (stats)
+      HIPCHK(c, hipMemcpyAsync(stats, c->mma_f, (size_t)B * GTOP_TRAJ_STATS * sizeof(double), hipMemcpyDeviceToHost,
+                               c->stream));
+    if (samples) HIPCHK(c, hipMemcpyAsync(samples, c->d_q, ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
@@ -669,6 +687,39 @@ int gtop_edt_query(gtop_ctx *c, int N, const double *pos, const double *time, do
   if ((rc = gtop_edt_query_device(c, N, dp, dt, dd, dg, c->stream))) return rc;
   HIPCHK(c, hipMemcpyAsync(dist, dd, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(grad, dg, 3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+}
+
+// EDTEnvironment::evaluateCoarseEDT (src/edt_environment.cpp:124-136)
+int gtop_edt_coarse_query_device(gtop_ctx *c, int N, const void *d_pos, const void *d_time, void *d_dist,
+                                 void *hip_stream) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!c->have_grid || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+  if (N < 0) return fail(c, GTOP_ERR_INVALID, "edt_coarse_query: N < 0");
+  if (N == 0) return GTOP_OK;
+  if (!d_pos || !d_time || !d_dist) return fail(c, GTOP_ERR_INVALID, "edt_coarse_query: NULL buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n3 = (size_t)c->nbox * 3;
+  HIPCHK(c, gtop_launch_edt_query(c->grid, c->sdf64, c->nbox, c->boxes, c->boxes + n3, c->boxes + 2 * n3, N,
+                                  static_cast<const double *>(d_pos), static_cast<const double *>(d_time),
+                                  static_cast<double *>(d_dist), nullptr, static_cast<hipStream_t>(hip_stream)));
+  return GTOP_OK;
+}
+
+int gtop_edt_coarse_query(gtop_ctx *c, int N, const double *pos, const double *time, double *dist) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (N < 0 || (N > 0 && (!pos || !time || !dist))) return fail(c, GTOP_ERR_INVALID, "edt_coarse_query: bad arguments");
+  if (N == 0) return GTOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  const size_t n = (size_t)N;
+  if ((rc = ensure(c, &c->d_q, &c->cap_q, 5 * n))) return rc;
+  double *dp = c->d_q, *dt = dp + 3 * n, *dd = dt + n;
+  HIPCHK(c, hipMemcpyAsync(dp, pos, 3 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dt, time, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if ((rc = gtop_edt_coarse_query_device(c, N, dp, dt, dd, c->stream))) return rc;
+  HIPCHK(c, hipMemcpyAsync(dist, dd, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 }

@@ -16,8 +16,16 @@
 // with a zero gradient (sdf_map.cpp:187).
 //
 // One lane per query; the boxes (a few dozen at most) sit in LDS and are walked
-// by every lane in step, so their reads are broadcasts.  fp64.  Gather-bound:
-// 8 corner loads + 64 B of query/result per lane.
+// by every lane in step, so their reads are broadcasts.  The N x 3 query
+// positions and gradients cross HBM as whole rows of the workgroup (768
+// consecutive doubles, transposed through LDS at an odd stride), not as
+// stride-3 accesses.  fp64.  Gather-bound: 8 corner loads (the corner pairs along
+// z share a sector) + 64 B of query/result per lane; algorithmic bytes per query
+// 8*8 + 4*8 + 4*8 = 128.
+// COARSE = EDTEnvironment::evaluateCoarseEDT (src/edt_environment.cpp:124-136):
+// the distance of the voxel holding the position (SDFMap::getDistance(pos),
+// src/sdf_map.cpp:155-164), min'ed with the box distance from the position
+// itself; no interpolation, no gradient.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,50 +36,65 @@ namespace {
 
 constexpr int kBoxChunk = 128;   // boxes staged in LDS per pass
 
+template <bool COARSE>
 __global__ void __launch_bounds__(256)
 edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, const double *__restrict__ box_p0,
                  const double *__restrict__ box_vel, const double *__restrict__ box_scale, int N,
                  const double *__restrict__ pos, const double *__restrict__ time, double *__restrict__ dist,
                  double *__restrict__ grad) {
   __shared__ double bx[kBoxChunk][9];   // p0, vel, scale
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double xyz[3 * 256];       // the workgroup's positions, later its gradients, as they lie in HBM
+  const int tid = threadIdx.x;
+  const size_t row0 = (size_t)blockIdx.x * 256;   // first query of the workgroup
+  const int i = (int)row0 + tid;
   const bool live = i < N;
-  double p[3] = {0, 0, 0}, t = -1.0;
-  if (live) {
-    p[0] = pos[3 * (size_t)i];
-    p[1] = pos[3 * (size_t)i + 1];
-    p[2] = pos[3 * (size_t)i + 2];
-    t = time[i];
+  const size_t n3 = 3 * (size_t)N;
+  for (int k = 0; k < 3; ++k) {
+    const size_t e = 3 * row0 + tid + 256 * k;
+    xyz[tid + 256 * k] = e < n3 ? pos[e] : 0.0;
   }
+  __syncthreads();
+  double p[3] = {xyz[3 * tid], xyz[3 * tid + 1], xyz[3 * tid + 2]};
+  const double t = live ? time[i] : -1.0;
   // isInMap, sdf_map.cpp:55-69
   bool out = false;
   for (int k = 0; k < 3; ++k) out |= (p[k] < g.min_range[k] + 1e-4) | (p[k] > g.max_range[k] - 1e-4);
-  // base index and diff, sdf_map.cpp:201-209
+  const bool dyn = live & (COARSE || !out) & (t >= 0.0);
   int idx[3];
-  double diff[3];
-  for (int k = 0; k < 3; ++k) {
-    const double pm = p[k] - 0.5 * g.res;
-    idx[k] = (int)floor((pm - g.origin[k]) * g.res_inv);
-    diff[k] = (p[k] - ((idx[k] + 0.5) * g.res + g.origin[k])) * g.res_inv;
-  }
+  double diff[3] = {0, 0, 0};
   double values[2][2][2];
+  double coarse = -1.0;   // COARSE: SDFMap::getDistance(pos)
+  if constexpr (COARSE) {
+    // posToIndex, sdf_map.cpp:71-74 (clamped for memory safety only: an in-map position indexes inside the grid)
+    for (int k = 0; k < 3; ++k) idx[k] = (int)floor((p[k] - g.origin[k]) * g.res_inv);
+    const int cx = min(max(idx[0], 0), g.nx - 1), cy = min(max(idx[1], 0), g.ny - 1), cz = min(max(idx[2], 0), g.nz - 1);
+    const double v = field[((size_t)cx * g.ny + cy) * g.nz + cz];
+    coarse = out ? -1.0 : v;
+  } else {
+    // base index and diff, sdf_map.cpp:201-209
+    for (int k = 0; k < 3; ++k) {
+      const double pm = p[k] - 0.5 * g.res;
+      idx[k] = (int)floor((pm - g.origin[k]) * g.res_inv);
+      diff[k] = (p[k] - ((idx[k] + 0.5) * g.res + g.origin[k])) * g.res_inv;
+    }
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y)
+      for (int y = 0; y < 2; ++y)
 #pragma unroll
-      for (int z = 0; z < 2; ++z) {
-        // getDistance(int,int,int): per-axis clamp, sdf_map.cpp:176-183
-        const int cx = min(max(idx[0] + x, 0), g.nx - 1), cy = min(max(idx[1] + y, 0), g.ny - 1),
-                  cz = min(max(idx[2] + z, 0), g.nz - 1);
-        values[x][y][z] = field[((size_t)cx * g.ny + cy) * g.nz + cz];
-      }
-  // min over the boxes at the 8 corner centres (edt_environment.cpp:26-73, :96-98)
-  const bool dyn = live & !out & (t >= 0.0);
+        for (int z = 0; z < 2; ++z) {
+          // getDistance(int,int,int): per-axis clamp, sdf_map.cpp:176-183
+          const int cx = min(max(idx[0] + x, 0), g.nx - 1), cy = min(max(idx[1] + y, 0), g.ny - 1),
+                    cz = min(max(idx[2] + z, 0), g.nz - 1);
+          values[x][y][z] = field[((size_t)cx * g.ny + cy) * g.nz + cz];
+        }
+  }
+  // min over the boxes (edt_environment.cpp:26-73): at the 8 corner centres (:96-98), or at the position (:131)
+  double dbox = 10000000.0;   // :64
   for (int b0 = 0; b0 < nbox; b0 += kBoxChunk) {
     const int nb = min(kBoxChunk, nbox - b0);
     __syncthreads();
-    for (int q = threadIdx.x; q < nb * 9; q += blockDim.x) {
+    for (int q = tid; q < nb * 9; q += blockDim.x) {
       const int b = q / 9, f = q - 9 * b;
       const double *src = f < 3 ? box_p0 : (f < 6 ? box_vel : box_scale);
       bx[b][f] = src[3 * (size_t)(b0 + b) + (f % 3)];
@@ -85,26 +108,39 @@ edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, c
           bmax[k] = c + 0.5 * bx[b][6 + k];
           bmin[k] = c - 0.5 * bx[b][6 + k];
         }
-        // per axis and corner offset: 0 inside the slab, else the distance to its nearer face (:36-40)
-        double d1[3][2];
-        for (int k = 0; k < 3; ++k)
-          for (int o = 0; o < 2; ++o) {
-            const double pt = (idx[k] + o + 0.5) * g.res + g.origin[k];
-            d1[k][o] = (pt >= bmin[k] && pt <= bmax[k]) ? 0.0 : fmin(fabs(pt - bmin[k]), fabs(pt - bmax[k]));
+        if constexpr (COARSE) {
+          double d2 = 0.0;
+          for (int k = 0; k < 3; ++k) {
+            const double dk = (p[k] >= bmin[k] && p[k] <= bmax[k]) ? 0.0 : fmin(fabs(p[k] - bmin[k]), fabs(p[k] - bmax[k]));
+            d2 += dk * dk;
           }
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int z = 0; z < 2; ++z) {
-              const double d2 = sqrt(d1[0][x] * d1[0][x] + d1[1][y] * d1[1][y] + d1[2][z] * d1[2][z]);   // dist.norm()
-              values[x][y][z] = d2 < values[x][y][z] ? d2 : values[x][y][z];
+          const double d = sqrt(d2);   // dist.norm()
+          dbox = d < dbox ? d : dbox;
+        } else {
+          // per axis and corner offset: 0 inside the slab, else the distance to its nearer face (:36-40)
+          double d1[3][2];
+          for (int k = 0; k < 3; ++k)
+            for (int o = 0; o < 2; ++o) {
+              const double pt = (idx[k] + o + 0.5) * g.res + g.origin[k];
+              d1[k][o] = (pt >= bmin[k] && pt <= bmax[k]) ? 0.0 : fmin(fabs(pt - bmin[k]), fabs(pt - bmax[k]));
             }
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+              for (int z = 0; z < 2; ++z) {
+                const double d2 = sqrt(d1[0][x] * d1[0][x] + d1[1][y] * d1[1][y] + d1[2][z] * d1[2][z]);   // dist.norm()
+                values[x][y][z] = d2 < values[x][y][z] ? d2 : values[x][y][z];
+              }
+        }
       }
     }
   }
-  if (!live) return;
+  if constexpr (COARSE) {
+    if (live) dist[i] = (t < 0.0) ? coarse : (coarse < dbox ? coarse : dbox);   // :125-135
+    return;
+  }
   // trilinear value and gradient, edt_environment.cpp:104-121 (= sdf_map.cpp:221-239)
   const double v00 = (1 - diff[0]) * values[0][0][0] + diff[0] * values[1][0][0];
   const double v01 = (1 - diff[0]) * values[0][0][1] + diff[0] * values[1][0][1];
@@ -119,10 +155,16 @@ edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, c
   gx += diff[2] * diff[1] * (values[1][1][1] - values[0][1][1]);
   const double gy = ((1 - diff[2]) * (v10 - v00) + diff[2] * (v11 - v01)) * g.res_inv;
   const double gz = (v1 - v0) * g.res_inv;
-  dist[i] = out ? -1.0 : d;
-  grad[3 * (size_t)i] = out ? 0.0 : gx * g.res_inv;
-  grad[3 * (size_t)i + 1] = out ? 0.0 : gy;
-  grad[3 * (size_t)i + 2] = out ? 0.0 : gz;
+  if (live) dist[i] = out ? -1.0 : d;
+  __syncthreads();   // every lane has read its position: the tile now carries the gradients out
+  xyz[3 * tid] = out ? 0.0 : gx * g.res_inv;
+  xyz[3 * tid + 1] = out ? 0.0 : gy;
+  xyz[3 * tid + 2] = out ? 0.0 : gz;
+  __syncthreads();
+  for (int k = 0; k < 3; ++k) {
+    const size_t e = 3 * row0 + tid + 256 * k;
+    if (e < n3) grad[e] = xyz[tid + 256 * k];
+  }
 }
 
 }  // namespace
@@ -131,7 +173,11 @@ hipError_t gtop_launch_edt_query(const GtopGrid &g, const double *field, int nbo
                                  const double *box_vel, const double *box_scale, int N, const double *pos,
                                  const double *time, double *dist, double *grad, hipStream_t stream) {
   if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(edt_query_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, g, field, nbox, box_p0, box_vel,
-                     box_scale, N, pos, time, dist, grad);
+  if (grad)
+    hipLaunchKernelGGL(edt_query_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, stream, g, field, nbox, box_p0,
+                       box_vel, box_scale, N, pos, time, dist, grad);
+  else   // evaluateCoarseEDT: no interpolation, no gradient
+    hipLaunchKernelGGL(edt_query_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, stream, g, field, nbox, box_p0,
+                       box_vel, box_scale, N, pos, time, dist, grad);
   return hipGetLastError();
 }

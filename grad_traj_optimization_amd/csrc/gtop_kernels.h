@@ -95,8 +95,10 @@ hipError_t gtop_launch_setup_paths(int B, int m, const double *wp, double mean_v
                                    double *Df, double *x0, hipStream_t stream);
 hipError_t gtop_launch_coefficients(int B, int m, const double *x, const double *Df, const double *T, int t_stride,
                                     double *coeff, hipStream_t stream);
+// samples (may be NULL): [B][max_samples][3] getTraj points
 hipError_t gtop_launch_eval_trajectories(int B, int m, const double *coeff, const double *T, int t_stride,
-                                         double dt_sample, double *out, hipStream_t stream);
+                                         double dt_sample, double *out, double *samples, int max_samples,
+                                         hipStream_t stream);
 
 // ---- static field + moving boxes (gtop_edt.hip) -----------------------------
 hipError_t gtop_launch_edt_query(const GtopGrid &g, const double *field, int nbox, const double *box_p0,

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gtop_device_common.h"
 #include "gtop_kernels.h"
 
 #pragma clang fp contract(off)   // keep the reference's unfused arithmetic (bit-exact setup)
@@ -66,93 +67,138 @@ __device__ __forceinline__ double poly_eval(const double *c, double t) {
   return s;
 }
 
+// PolynomialTraj's evaluation of one optimised trajectory (polynomial_traj.hpp:37-204), one WAVEFRONT per
+// trajectory:
+//   * getTraj / getLength (:69-92): the samples every dt_sample are spread over the lanes, 64 at a time.  The
+//     reference accumulates the sample time (eval_t += 0.01) and tests eval_t <= time_sum, so the time of sample
+//     k is that sum, not k*dt: every chunk starts from the carried accumulated value and lane l adds dt l times
+//     (64 predicated additions per chunk, nothing next to the 18 pow() of a sample) — sample count and sample
+//     times are the reference's exactly.  A lane's neighbour's point arrives through a wavefront shuffle, the
+//     previous chunk's last point through a broadcast; the length is a wavefront sum (summation order differs from
+//     the serial sum: ~1e-16).
+//   * getAccCost, getJerk, getMeanAndMaxVel/Acc (:96-204): one lane per segment, then wavefront sums / maxima.
+//     Quirk kept: the velocity/acceleration "samples" use pow(ts, i) — the segment DURATION — so each is the
+//     segment's end-point value, counted once per accumulated eval_t < ts.
+// samples (may be NULL): [B][max_samples][3], the getTraj points; stats[8] = their number (also when it exceeds
+// max_samples: then only the first max_samples are stored).
+// Bound: VALU (the pow() calls, kept for 1e-9 agreement with the reference's evaluation order); 24 B per sample out.
 __global__ void __launch_bounds__(64)
 eval_trajectories_kernel(int B, int m, const double *__restrict__ coeff, const double *__restrict__ T,
-                         int t_stride, double dt_sample, double *__restrict__ out /*[B][GTOP_TRAJ_STATS]*/) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+                         int t_stride, double dt_sample, double *__restrict__ out /*[B][GTOP_TRAJ_STATS]*/,
+                         double *__restrict__ samples, int max_samples) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
   const double *cf = coeff + (size_t)b * m * 18;   // row s = [cx0..5 | cy0..5 | cz0..5], ascending powers
   const double *ts = T + (size_t)b * t_stride;
   double time_sum = 0.0;                            // init(), :37-43
   for (int s = 0; s < m; ++s) time_sum += ts[s];
 
-  // getTraj + getLength (:69-92): samples every dt_sample (0.01 in the reference), eval_t accumulated
-  double length = 0.0, pl[3] = {0, 0, 0};
+  // ---- getTraj + getLength ----
+  double length = 0.0, base_t = 0.0, carry[3] = {0, 0, 0};
   int nsamp = 0;
-  for (double eval_t = 0.0; eval_t <= time_sum; eval_t += dt_sample) {
-    double t = eval_t;
-    int idx = 0;
-    while (idx < m - 1 && ts[idx] <= t) {   // :48-51; the reference walks off the end when t == time_sum exactly,
-      t -= ts[idx];                          // here the last segment is extended instead
-      ++idx;
-    }
-    double pn[3];
-    for (int a = 0; a < 3; ++a) pn[a] = poly_eval(cf + idx * 18 + 6 * a, t);
-    if (nsamp > 0) {
-      const double dx = pn[0] - pl[0], dy = pn[1] - pl[1], dz = pn[2] - pl[2];
-      length += sqrt(dx * dx + dy * dy + dz * dz);
-    }
-    pl[0] = pn[0]; pl[1] = pn[1]; pl[2] = pn[2];
-    ++nsamp;
-  }
-
-  // getAccCost (:96-109): um = 2 * (coefficient of t^2) = a(0) per segment
-  double acc_cost = 0.0;
-  for (int s = 0; s < m; ++s) {
-    const double ux = 2 * cf[s * 18 + 2], uy = 2 * cf[s * 18 + 8], uz = 2 * cf[s * 18 + 14];
-    acc_cost += (ux * ux + uy * uy + uz * uz) * ts[s];
-  }
-
-  // getJerk (:111-142): c' M c with M(i,j) = i(i-1)(i-2) j(j-1)(j-2) ts^(i+j-5) / (i+j-5), i,j = 3..5
-  double jerk = 0.0;
-  for (int s = 0; s < m; ++s) {
-    for (int a = 0; a < 3; ++a) {
-      const double *c = cf + s * 18 + 6 * a;
-      double acc = 0.0;
-      for (int j = 3; j < 6; ++j) {      // (c' M)(j) then . c, as Eigen evaluates c.transpose() * M * c
-        double col = 0.0;
-        for (int i = 3; i < 6; ++i) {
-          const double di = i, dj = j;
-          col += c[i] * (di * (di - 1) * (di - 2) * dj * (dj - 1) * (dj - 2) * pow(ts[s], di + dj - 5) / (di + dj - 5));
-        }
-        acc += col * c[j];
+  bool first_chunk = true;
+  while (base_t <= time_sum) {                      // wave-uniform: base_t is the time of the chunk's sample 0
+    double eval_t = base_t;
+    for (int i = 0; i < lane; ++i) eval_t += dt_sample;          // the accumulated time of sample chunk*64 + lane
+    double next_base = base_t;
+    for (int i = 0; i < 64; ++i) next_base += dt_sample;
+    const bool live = eval_t <= time_sum;           // monotone in the lane index
+    double pn[3] = {0, 0, 0};
+    if (live) {
+      double t = eval_t;
+      int idx = 0;
+      while (idx < m - 1 && ts[idx] <= t) {   // :48-51; the reference walks off the end when t == time_sum exactly,
+        t -= ts[idx];                          // here the last segment is extended instead
+        ++idx;
       }
-      jerk += acc;
+      for (int a = 0; a < 3; ++a) pn[a] = poly_eval(cf + idx * 18 + 6 * a, t);
+      if (samples && nsamp + lane < max_samples) {
+        double *o = samples + ((size_t)b * max_samples + nsamp + lane) * 3;
+        o[0] = pn[0]; o[1] = pn[1]; o[2] = pn[2];
+      }
     }
-  }
-
-  // getMeanAndMaxVel / Acc (:144-204).  Quirk kept: the time vector is built from
-  // pow(ts, i) — the segment DURATION, not eval_t — so every sample of a segment is
-  // its end-point velocity / acceleration; the loop only sets how often it is counted.
-  double mean_v = 0.0, max_v = -1.0, mean_a = 0.0, max_a = -1.0;
-  int num_v = 0, num_a = 0;
-  for (int s = 0; s < m; ++s) {
-    double vel[3], acc[3];
+    // previous point: lane - 1's, or the last point of the previous chunk
+    double pl[3];
     for (int a = 0; a < 3; ++a) {
-      const double *c = cf + s * 18 + 6 * a;
-      double sv = 0.0, sa = 0.0;
-      for (int i = 0; i < 5; ++i) sv += pow(ts[s], (double)i) * ((double)(i + 1) * c[i + 1]);
-      for (int i = 0; i < 4; ++i) sa += pow(ts[s], (double)i) * ((double)((i + 2) * (i + 1)) * c[i + 2]);
-      vel[a] = sv;
-      acc[a] = sa;
+      const double up = __shfl_up(pn[a], 1);
+      pl[a] = lane == 0 ? carry[a] : up;
     }
-    const double vn = sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
-    const double an = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
-    for (double eval_t = 0.0; eval_t < ts[s]; eval_t += dt_sample) {
-      mean_v += vn;
-      if (vn > max_v) max_v = vn;
-      ++num_v;
-      mean_a += an;
-      if (an > max_a) max_a = an;
-      ++num_a;
+    double seg = 0.0;
+    if (live && !(first_chunk && lane == 0)) {
+      const double dx = pn[0] - pl[0], dy = pn[1] - pl[1], dz = pn[2] - pl[2];
+      seg = sqrt(dx * dx + dy * dy + dz * dz);
     }
+    length += gtop_wave_sum(seg);
+    const unsigned long long mask = __ballot(live);
+    const int cnt = __popcll(mask);
+    nsamp += cnt;
+    for (int a = 0; a < 3; ++a) carry[a] = __shfl(pn[a], cnt - 1);   // (cnt >= 1: lane 0 is live)
+    first_chunk = false;
+    base_t = next_base;
   }
-  mean_v = mean_v / (double)num_v;
-  mean_a = mean_a / (double)num_a;
 
-  double *o = out + (size_t)b * GTOP_TRAJ_STATS;
-  o[0] = time_sum; o[1] = length; o[2] = jerk; o[3] = mean_v; o[4] = max_v;
-  o[5] = mean_a; o[6] = max_a; o[7] = acc_cost; o[8] = (double)nsamp;
+  // ---- per-segment quantities: lane s < m (m <= 64 per pass) ----
+  double acc_cost = 0.0, jerk = 0.0, sum_v = 0.0, sum_a = 0.0, max_v = -1.0, max_a = -1.0;
+  int num = 0;
+  for (int s0 = 0; s0 < m; s0 += 64) {
+    const int s = s0 + lane;
+    double ac = 0.0, jk = 0.0, sv_tot = 0.0, sa_tot = 0.0, vn = -1.0, an = -1.0;
+    int c = 0;
+    if (s < m) {
+      const double Ts = ts[s];
+      // getAccCost (:96-109): um = 2 * (coefficient of t^2) = a(0) per segment
+      const double ux = 2 * cf[s * 18 + 2], uy = 2 * cf[s * 18 + 8], uz = 2 * cf[s * 18 + 14];
+      ac = (ux * ux + uy * uy + uz * uz) * Ts;
+      // getJerk (:111-142): c' M c with M(i,j) = i(i-1)(i-2) j(j-1)(j-2) ts^(i+j-5) / (i+j-5), i,j = 3..5
+      for (int a = 0; a < 3; ++a) {
+        const double *cc = cf + s * 18 + 6 * a;
+        double acc = 0.0;
+        for (int j = 3; j < 6; ++j) {      // (c' M)(j) then . c, as Eigen evaluates c.transpose() * M * c
+          double col = 0.0;
+          for (int i = 3; i < 6; ++i) {
+            const double di = i, dj = j;
+            col += cc[i] * (di * (di - 1) * (di - 2) * dj * (dj - 1) * (dj - 2) * pow(Ts, di + dj - 5) / (di + dj - 5));
+          }
+          acc += col * cc[j];
+        }
+        jk += acc;
+      }
+      // getMeanAndMaxVel / Acc (:144-204)
+      double vel[3], acc3[3];
+      for (int a = 0; a < 3; ++a) {
+        const double *cc = cf + s * 18 + 6 * a;
+        double sv = 0.0, sa = 0.0;
+        for (int i = 0; i < 5; ++i) sv += pow(Ts, (double)i) * ((double)(i + 1) * cc[i + 1]);
+        for (int i = 0; i < 4; ++i) sa += pow(Ts, (double)i) * ((double)((i + 2) * (i + 1)) * cc[i + 2]);
+        vel[a] = sv;
+        acc3[a] = sa;
+      }
+      vn = sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+      an = sqrt(acc3[0] * acc3[0] + acc3[1] * acc3[1] + acc3[2] * acc3[2]);
+      for (double eval_t = 0.0; eval_t < Ts; eval_t += dt_sample) {   // accumulated, as the reference's loops
+        sv_tot += vn;
+        sa_tot += an;
+        ++c;
+      }
+      if (c == 0) vn = an = -1.0;   // a segment without a sample does not enter the maxima
+    }
+    acc_cost += gtop_wave_sum(ac);
+    jerk += gtop_wave_sum(jk);
+    sum_v += gtop_wave_sum(sv_tot);
+    sum_a += gtop_wave_sum(sa_tot);
+    num += (int)gtop_wave_sum((double)c);
+    for (int off = 32; off > 0; off >>= 1) {
+      vn = fmax(vn, __shfl_xor(vn, off));
+      an = fmax(an, __shfl_xor(an, off));
+    }
+    max_v = fmax(max_v, vn);
+    max_a = fmax(max_a, an);
+  }
+  if (lane == 0) {
+    double *o = out + (size_t)b * GTOP_TRAJ_STATS;
+    o[0] = time_sum; o[1] = length; o[2] = jerk; o[3] = sum_v / (double)num; o[4] = max_v;
+    o[5] = sum_a / (double)num; o[6] = max_a; o[7] = acc_cost; o[8] = (double)nsamp;
+  }
 }
 
 // coefficients from derivatives for B trajectories (getCoefficientFromDerivative,
@@ -202,9 +248,10 @@ hipError_t gtop_launch_coefficients(int B, int m, const double *x, const double 
 }
 
 hipError_t gtop_launch_eval_trajectories(int B, int m, const double *coeff, const double *T, int t_stride,
-                                         double dt_sample, double *out, hipStream_t stream) {
+                                         double dt_sample, double *out, double *samples, int max_samples,
+                                         hipStream_t stream) {
   if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(eval_trajectories_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, B, m, coeff, T, t_stride,
-                     dt_sample, out);
+  hipLaunchKernelGGL(eval_trajectories_kernel, dim3(B), dim3(64), 0, stream, B, m, coeff, T, t_stride, dt_sample, out,
+                     samples, max_samples);
   return hipGetLastError();
 }

@@ -265,10 +265,22 @@ int gtop_eval_trajectories_device(gtop_ctx *ctx, int B, int m, const void *d_coe
                                   const void *d_T, int time_stride,
                                   double dt_sample, void *d_stats,
                                   void *hip_stream);
+/* The same, also returning the points PolynomialTraj::getTraj produces
+ * (polynomial_traj.hpp:69-78: one every dt_sample, the sample time ACCUMULATED
+ * as the reference does, while eval_t <= time_sum): samples is
+ * B x max_samples x 3; trajectory b has stats[b][8] points, of which the first
+ * min(stats[b][8], max_samples) are stored.  src/opti_node.cpp:108-120 publishes
+ * exactly these. */
+int gtop_sample_trajectories_device(gtop_ctx *ctx, int B, int m, const void *d_coeff,
+                                    const void *d_T, int time_stride, double dt_sample,
+                                    void *d_stats, void *d_samples, int max_samples,
+                                    void *hip_stream);
 /* Host-buffer form for the context's problem: coefficients (may be NULL) and
  * stats (may be NULL) of the first B trajectories at free variables x. */
 int gtop_trajectory_stats(gtop_ctx *ctx, int B, const double *x, double dt_sample,
                           double *coeff, double *stats);
+int gtop_trajectory_samples(gtop_ctx *ctx, int B, const double *x, double dt_sample,
+                            double *coeff, double *stats, double *samples, int max_samples);
 
 /* Distance queries against the static field plus moving obstacles:
  * EDTEnvironment::evaluateEDTWithGrad / distToBox / minDistToAllBox
@@ -286,6 +298,14 @@ int gtop_edt_query_device(gtop_ctx *ctx, int N, const void *d_pos,
                           void *hip_stream);
 int gtop_edt_query(gtop_ctx *ctx, int N, const double *pos, const double *time,
                    double *dist, double *grad);
+/* EDTEnvironment::evaluateCoarseEDT (src/edt_environment.cpp:124-136): no
+ * interpolation and no gradient — the distance stored in the voxel that holds
+ * pos (SDFMap::getDistance(pos), src/sdf_map.cpp:155-164; -1 outside the map),
+ * and for time >= 0 its minimum with the distance from pos to the nearest box. */
+int gtop_edt_coarse_query_device(gtop_ctx *ctx, int N, const void *d_pos,
+                                 const void *d_time, void *d_dist, void *hip_stream);
+int gtop_edt_coarse_query(gtop_ctx *ctx, int N, const double *pos, const double *time,
+                          double *dist);
 
 /* ---- bookkeeping the reference keeps inside the callback ------------ */
 

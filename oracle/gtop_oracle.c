@@ -388,6 +388,22 @@ static double edt_min_dist_to_boxes(int nbox, const double *p0, const double *ve
   return dist;
 }
 
+/* EDTEnvironment::evaluateCoarseEDT, src/edt_environment.cpp:124-136: the distance of the voxel that holds
+ * `pos` (SDFMap::getDistance(Vector3d), src/sdf_map.cpp:155-164: -1 outside the map), and with time >= 0 its
+ * minimum with the distance from `pos` itself to the nearest moving box.  No interpolation, no gradient. */
+double oracle_edt_coarse(const oracle_sdf *S, int nbox, const double *box_p0, const double *box_vel,
+                         const double *box_scale, const double pos[3], double time) {
+  double d1 = -1.0;
+  if (sdf_in_map(S, pos)) {
+    int id[3];
+    sdf_pos_to_index(S, pos, id);
+    d1 = sdf_get_distance(S, id[0], id[1], id[2]);
+  }
+  if (time < 0.0) return d1;
+  double d2 = edt_min_dist_to_boxes(nbox, box_p0, box_vel, box_scale, pos, time);
+  return d1 < d2 ? d1 : d2;
+}
+
 /* EDTEnvironment::evaluateEDTWithGrad, src/edt_environment.cpp:75-122: the
  * trilinear value/gradient over corner values min(static distance, distance
  * to the nearest moving box at `time`); time < 0 means static only (:91-94).
@@ -774,6 +790,27 @@ static double traj_poly_eval(const double *c, double t) {
  * coeff: m x 18 (row s = [cx0..5 | cy0..5 | cz0..5]).  dt_sample = 0.01 in the reference.
  * Convention where the reference has UB: evaluate() walks past the last segment when
  * t == time_sum exactly (:48-51); the last segment is extended instead. */
+/* PolynomialTraj::getTraj, polynomial_traj.hpp:69-78: the points every dt_sample (0.01 in the reference), the
+ * sample time accumulated; returns their number and stores the first max_samples of them. */
+int oracle_traj_samples(int m, const double *coeff, const double *T, double dt_sample, int max_samples,
+                        double *samples) {
+  double time_sum = 0.0;
+  for (int i = 0; i < m; ++i) time_sum += T[i];
+  int nsamp = 0;
+  for (double eval_t = 0.0; eval_t <= time_sum; eval_t += dt_sample) {
+    double t = eval_t;
+    int idx = 0;
+    while (idx < m - 1 && T[idx] <= t) {
+      t -= T[idx];
+      ++idx;
+    }
+    if (nsamp < max_samples)
+      for (int a = 0; a < 3; ++a) samples[3 * nsamp + a] = traj_poly_eval(coeff + idx * 18 + 6 * a, t);
+    ++nsamp;
+  }
+  return nsamp;
+}
+
 void oracle_traj_stats(int m, const double *coeff, const double *T, double dt_sample, double *out) {
   double time_sum = 0.0; /* :37-43 */
   for (int i = 0; i < m; ++i) time_sum += T[i];

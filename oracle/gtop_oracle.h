@@ -65,6 +65,12 @@ double oracle_eval_batch(int B, int m, const double *T, int t_stride,
                          double *grad, int reps, int nthreads);
 
 void oracle_traj_stats(int m, const double *coeff, const double *T, double dt_sample, double *out);
+/* PolynomialTraj::getTraj (polynomial_traj.hpp:69-78): returns the number of points, stores the first max_samples */
+int oracle_traj_samples(int m, const double *coeff, const double *T, double dt_sample, int max_samples,
+                        double *samples);
+/* EDTEnvironment::evaluateCoarseEDT (src/edt_environment.cpp:124-136) */
+double oracle_edt_coarse(const oracle_sdf *S, int nbox, const double *box_p0, const double *box_vel,
+                         const double *box_scale, const double pos[3], double time);
 void oracle_coefficients(int m, const double *L, const double *Df, const double *x, double *coe);
 
 #ifdef __cplusplus

@@ -83,6 +83,10 @@ def lib():
         L.oracle_eval_batch.restype = C.c_double
         L.oracle_traj_stats.argtypes = [C.c_int, dp, dp, C.c_double, dp]
         L.oracle_traj_stats.restype = None
+        L.oracle_traj_samples.argtypes = [C.c_int, dp, dp, C.c_double, C.c_int, dp]
+        L.oracle_traj_samples.restype = C.c_int
+        L.oracle_edt_coarse.argtypes = [C.POINTER(OracleSdf), C.c_int, dp, dp, dp, dp, C.c_double]
+        L.oracle_edt_coarse.restype = C.c_double
         L.oracle_coefficients.argtypes = [C.c_int, dp, dp, dp, dp]
         L.oracle_coefficients.restype = None
         _lib = L
@@ -187,6 +191,15 @@ class Sdf:
             g[i] = gi
         return d, g
 
+    def edt_coarse(self, pos, time, p0, vel, scale):
+        """EDTEnvironment::evaluateCoarseEDT for each (pos, time)."""
+        pos = _f64(pos).reshape(-1, 3)
+        time = _f64(np.broadcast_to(time, (pos.shape[0],)))
+        p0, vel, scale = (_f64(a).reshape(-1, 3) for a in (p0, vel, scale))
+        return np.array([lib().oracle_edt_coarse(C.byref(self.c), p0.shape[0], _p(p0), _p(vel), _p(scale),
+                                                 _p(np.ascontiguousarray(pos[i])), float(time[i]))
+                         for i in range(pos.shape[0])])
+
     def build_from_points(self, pts):
         """updateSDFMap (grad_traj_optimizer.cpp:117-126): reset, mark, EDT."""
         occ = np.zeros(self.dist.size)
@@ -251,3 +264,11 @@ def traj_stats(coeff, T, dt_sample=0.01):
     out = np.zeros(9)
     lib().oracle_traj_stats(T.shape[0], _p(_f64(coeff)), _p(T), float(dt_sample), _p(out))
     return out
+
+
+def traj_samples(coeff, T, dt_sample=0.01, max_samples=4096):
+    """PolynomialTraj::getTraj: (count, points (min(count, max_samples), 3))."""
+    T = _f64(T)
+    buf = np.zeros((max_samples, 3))
+    n = lib().oracle_traj_samples(T.shape[0], _p(_f64(coeff)), _p(T), float(dt_sample), int(max_samples), _p(buf))
+    return n, buf[:min(n, max_samples)]

@@ -73,3 +73,25 @@ def test_device_entry_matches_host_entry(scene):
     dd, gd = ctx.edt_query_device(torch.tensor(pos, device=dev), torch.tensor(time, device=dev))
     torch.cuda.synchronize()
     assert np.array_equal(dd.cpu().numpy(), d) and np.array_equal(gd.cpu().numpy(), g)
+
+
+@pytest.mark.parametrize("nbox", [0, 5, 150])
+def test_coarse_query_parity(scene, oracle_mod, nbox):
+    """EDTEnvironment::evaluateCoarseEDT (src/edt_environment.cpp:124-136): the voxel's own distance
+    (SDFMap::getDistance(pos), sdf_map.cpp:155-164) min'ed with the box distance from the position itself."""
+    mp, ctx, sdf = scene
+    rng = np.random.default_rng(300 + nbox)
+    p0 = rng.uniform(mp.origin, mp.origin + mp.map_size, size=(nbox, 3))
+    vel = rng.uniform(-1.0, 1.0, size=(nbox, 3))
+    scale = rng.uniform(0.3, 1.5, size=(nbox, 3))
+    pos, time = _queries(mp, 1500, 40 + nbox)       # 1500: a partial last workgroup
+    ctx.set_moving_boxes(p0, vel, scale)
+    d = ctx.edt_coarse_query(pos, time)
+    d_ref = sdf.edt_coarse(pos, time, p0, vel, scale)
+    assert np.allclose(d, d_ref, rtol=1e-13, atol=1e-13)
+    assert ((d == -1.0) == (d_ref == -1.0)).all() and (d == -1.0).any()
+    # static only = the voxel value, bit for bit
+    ds = ctx.edt_coarse_query(pos, -1.0)
+    inside = ds != -1.0
+    idx = np.floor((pos[inside] - mp.origin) / mp.resolution).astype(int)
+    assert np.array_equal(ds[inside], sdf.dist.reshape(sdf.grid)[idx[:, 0], idx[:, 1], idx[:, 2]])

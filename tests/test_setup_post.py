@@ -68,3 +68,26 @@ def test_trajectory_stats_and_coefficients(gtop, oracle_mod):
             s_ref = oracle_mod.traj_stats(coeff[i], b.T[i], 0.01)
             assert stats[i, 8] == s_ref[8] and stats[i, 0] == s_ref[0]       # sample count, time sum: exact
             assert np.allclose(stats[i, 1:8], s_ref[1:8], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_trajectory_samples_are_the_gettraj_points(gtop, oracle_mod):
+    """PolynomialTraj::getTraj (polynomial_traj.hpp:69-78), what src/opti_node.cpp:108-120 publishes: one point
+    every 0.01 s with the sample time accumulated; count exact, points to 1e-9 (pow() differs in the last bits)."""
+    mp = problem.make_map((40, 40, 20), density=0.0, seed=1)
+    ctx = gtop.GtopContext(device=0)
+    for m, cap in ((2, 4096), (6, 4096), (6, 100)):          # cap 100: more points than the buffer holds
+        b = problem.make_trajectories(9, m, mp, seed=80 + m, step_len=(0.5, 1.5), margin=0.4)
+        x = b.x + np.random.default_rng(m).normal(0, 0.3, b.x.shape)
+        ctx.set_problem(b.T, b.Df)
+        coeff, stats0 = ctx.trajectory_stats(x, dt_sample=0.01)
+        stats, samples = ctx.trajectory_samples(x, dt_sample=0.01, max_samples=cap)
+        assert np.array_equal(stats, stats0)                 # the same kernel with the sample output on
+        for i in range(9):
+            n_ref, pts_ref = oracle_mod.traj_samples(coeff[i], b.T[i], 0.01, max_samples=cap)
+            assert stats[i, 8] == n_ref and n_ref > 64       # several 64-sample chunks
+            k = min(n_ref, cap)
+            assert np.allclose(samples[i, :k], pts_ref, rtol=1e-9, atol=1e-9)
+            assert np.all(samples[i, k:] == 0.0)             # nothing written past the count / the cap
+        # first point = start waypoint, consecutive points 0.01 s apart along the path
+        assert np.allclose(samples[:, 0], b.Df[:, :, 0], atol=1e-12)
