@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 --pmc CSVs written by tools/pmc_collect.sh: per-launch
-averages for gtop_eval_kernel, plus the HBM-traffic figure used by bench.py's
+averages for the evaluation kernel (gtop_eval_kernel / gtop_eval_wave_kernel), plus the HBM-traffic figure used by bench.py's
 roofline.traffic.
 
 Traffic rule (MI355X_MICROARCH.md §HBM): FETCH_SIZE/WRITE_SIZE are in KiB;
@@ -20,10 +20,16 @@ def main():
     d = sys.argv[1]
     min_grid = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     avg = {}
-    for f in sorted(glob.glob(f"{d}/pass*/**/*counter_collection.csv", recursive=True)):
+    import os
+    passes = sorted(glob.glob(f"{d}/pass*/"))
+    for pd in passes:
+        cands = glob.glob(f"{pd}/**/*counter_collection.csv", recursive=True)
+        if not cands:
+            continue
+        f = max(cands, key=os.path.getmtime)     # gpurun merges into an existing directory: take the newest run only
         acc = defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "gtop_eval_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) >= min_grid:
+            if "gtop_eval" in r["Kernel_Name"] and int(r["Grid_Size"]) >= min_grid:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             v = v[len(v) // 4:]          # drop the first quarter (warm-up / parity launches)
