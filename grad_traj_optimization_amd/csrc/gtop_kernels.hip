@@ -1049,11 +1049,23 @@ gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
 // (-amdgpu-kernarg-preload-count, csrc/Makefile): measured with s_memtime stamps, a lone wavefront otherwise
 // waits ~1 100 cycles for its kernel-argument fetch before it can even request its inputs.  The rest of the
 // arguments (`a`; its x/Df/T/sdf/B/m/t_stride/nx/ny/nz fields are not read) arrive while the inputs do.
-template <typename R, bool WIDE, int SPL, int NT, bool COLLI>
-__global__ void __launch_bounds__(64)
+// The fp64 constants of the closed forms that are neither inline operands (0.5, 1, 2, 4) nor VOP2 literals: as
+// literals each costs an s_mov pair in front of its use (43 of them, every one a 4-cycle issue slot of a lone
+// wavefront); as kernel arguments they arrive in SGPRs with the rest of the argument block.
+template <typename R>
+struct GtopWaveConsts {
+  R q36 = 36, q72 = 72, q120 = 120, q192 = 192, q360 = 360, q720 = 720;   // jerk Hessian, src/qp_generator.cpp:226-234
+  R k10 = 10, k15 = 15, k7 = 7, k6 = 6, k3 = 3, k8 = 8, k1p5 = 1.5, k5 = 5;   // A_s^-1 / A_s^-T / d/dt of the powers
+  R eps = 1e-5;                                                           // :358
+};
+
+// MINW = wavefronts per SIMD the register budget must leave room for: 2 in the latency regime (constants pinned
+// in VGPRs, 232 of them), 3 for batches that can fill a third (no pins; 168-VGPR budget).
+template <typename R, bool WIDE, int SPL, int NT, bool COLLI, int MINW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MINW)))
 gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df, const R *__restrict__ arg_T,
                       const R *__restrict__ arg_sdf, int arg_B, int arg_m, int arg_t_stride, int arg_nx, int arg_ny,
-                      int arg_nz, const GtopKernelArgs<R> arg_rest) {
+                      int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K) {
   GtopKernelArgs<R> a = arg_rest;
   a.x = arg_x; a.Df = arg_Df; a.T = arg_T; a.sdf = arg_sdf;
   a.B = arg_B; a.m = arg_m; a.t_stride = arg_t_stride;
@@ -1135,13 +1147,20 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     offA[r] = okq[r] ? (rowB + 1) * kStride + sA * LPS : 0;
     offB[r] = okq[r] ? rowB * kStride + (sA + 1) * LPS : 0;
   }
+  // The scalar cost takes the same road: row 18 of the tile holds the lanes' cost accumulators, and lanes 48 .. 48+m-1
+  // (idle in the sum above: n <= 45) each sum one segment's ten with the very instructions the free variables use;
+  // three DPP row shifts then add the (at most six) segment sums.  (A 64-lane DPP sum of the accumulators was 46
+  // instructions of a lone wavefront's issue time.)
+  static_assert(NT == 1 && SPL == 3, "cost lanes 48..53 assume one trajectory of at most 6 segments per wavefront");
+  const bool cost_lane = (lane >= 48) & (lane < 48 + m);
+  if (cost_lane) offA[0] = 18 * kStride + (lane - 48) * LPS;
   const R ws = a.ws;   // the launcher has applied :412-415 (step 1 -> ws = 0): `step` is not read here
   const R wc = a.wc;
   ExpConsts expk;
   R pen_d0 = a.d0, pen_inv_r = a.inv_r, pen_alpha = a.alpha, pen_gd = -a.alpha_over_r;   // (:507-515)
   MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
                       {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
-  if constexpr (COLLI && !kIsF32<R>) {
+  if constexpr (COLLI && !kIsF32<R> && MINW <= 2) {
     expk.pin();
     mapbox.pin();
   }
@@ -1155,7 +1174,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   const R iT = fast_rcp(T), iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
   // :351, dt = T/30.  The quotient proper (a dozen instructions) is only needed where the sample COUNT hangs on
   // the accumulated sample time (tiny T, below); everywhere else T * (1/30) is the same to an ulp.
-  R dt = T * (R)(1.0 / 30.0);
+  const R dt = T * (R)(1.0 / 30.0);
   const R wdt = wc * dt;
   R q[3][6];
 #pragma unroll
@@ -1166,16 +1185,16 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     const R V = (vT - v0 - a0 * T) * T;
     const R A = (aT - a0) * T2;
     q[k][0] = p0; q[k][1] = v0; q[k][2] = (R)0.5 * a0;
-    q[k][3] = ((R)10 * P - (R)4 * V + (R)0.5 * A) * iT3;
-    q[k][4] = ((R)-15 * P + (R)7 * V - A) * iT4;
-    q[k][5] = ((R)6 * P - (R)3 * V + (R)0.5 * A) * iT5;
+    q[k][3] = (K.k10 * P - (R)4 * V + (R)0.5 * A) * iT3;
+    q[k][4] = (K.k7 * V - K.k15 * P - A) * iT4;
+    q[k][5] = (K.k6 * P - K.k3 * V + (R)0.5 * A) * iT5;
   }
   // The jerk term, as the START value of the accumulators (a lambda: it is placed where the distance-field
   // loads are in flight, see below).  Jerk Hessian Q_s: src/qp_generator.cpp:226-234, i,j in {3,4,5}.
   R acc[kRedVals];
   auto jerk_init = [&]() {
-    const R Q33 = (R)36 * T, Q34 = (R)72 * T2, Q35 = (R)120 * T3, Q44 = (R)192 * T3, Q45 = (R)360 * T4,
-            Q55 = (R)720 * T5;
+    const R Q33 = K.q36 * T, Q34 = K.q72 * T2, Q35 = K.q120 * T3, Q44 = K.q192 * T3, Q45 = K.q360 * T4,
+            Q55 = K.q720 * T5;
     // lane 0 of a segment carries the segment's jerk term into the sums
     const R wj = (seg_ok & (li == 0)) ? ws : (R)0;
     const R wj2 = wj + wj;
@@ -1200,89 +1219,104 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // sample COUNT depends on the accumulated value) replay the reference's addition chain.
     // Every term of a sample carries the factor alpha * wc * dt (cd of :509 times the weights of :373/:417);
     // a sample past the loop bound of :353 contributes nothing, i.e. has that factor zero.  With T >= 0.0301
-    // all 30 samples are inside the bound, so only the replay path below ever has to clear it.
-    R ts[SPL], aw[SPL];
-#pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-      ts[j] = (R)(li + j * LPS) * dt + (R)1e-3;
-      aw[j] = pen_alpha * wdt;
-    }
+    // all 30 samples are inside the bound, so only the replay path ever has to clear it.
+    // Sample times (:353, see gtop_eval_kernel): t_i = 1e-3 + i*dt; segments with T < 0.0301 (where the
+    // sample COUNT depends on the accumulated value) replay the reference's addition chain.
     const bool tiny_T = T < (R)0.0301;
-    if (__ballot(tiny_T) != 0ull) {   // wave-uniform, rare
-      if (tiny_T) {
-        dt = T / (R)30.0;
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-          R t = (R)1e-3;
-          for (int i = 0; i < li + j * LPS; ++i) t += dt;
-          ts[j] = t;
-          aw[j] = (t < T) ? pen_alpha * (wc * dt) : (R)0;
+    const bool any_tiny = __ballot(tiny_T) != 0ull;   // wave-uniform, rare
+    auto sample_time = [&](int j, R &t, R &awj) {
+      t = (R)(li + j * LPS) * dt + (R)1e-3;
+      awj = pen_alpha * wdt;
+      if (any_tiny) {
+        if (tiny_T) {
+          const R dtq = T / (R)30.0;   // the quotient proper, :351
+          t = (R)1e-3;
+          for (int i = 0; i < li + j * LPS; ++i) t += dtq;
+          awj = (t < T) ? pen_alpha * (wc * dtq) : (R)0;
         }
       }
+    };
+    constexpr int NTS = (MINW <= 2) ? SPL : 1;   // latency regime: all sample times before the first load
+    R ts[NTS], aw[NTS];
+    if constexpr (MINW <= 2) {
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) sample_time(j, ts[j], aw[j]);
     }
-    // stage A: positions, index arithmetic, all corner loads in flight
-    R vels[SPL][3];
-    SdfTap<R> taps[SPL];
+    // The samples of a lane go through two stages, CH at a time.  Latency regime (MINW = 2): CH = SPL, all 12 corner
+    // loads of the lane in flight at once, the jerk term and the speeds computed behind them, the order pinned by
+    // scheduling barriers.  Throughput regime (MINW = 3): one sample at a time — other wavefronts cover the loads,
+    // and only one sample's corners are live (the 168-VGPR budget of a third wavefront).
+    constexpr int CH = (MINW <= 2) ? SPL : 1;
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-      const R t = ts[j];
-      const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-      const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;   // d/dt of the powers
-      R pos[3];
+    for (int j0 = 0; j0 < SPL; j0 += CH) {
+      // stage A: positions, index arithmetic, corner loads
+      R vels[CH][3];
+      SdfTap<R> taps[CH];
+      if constexpr (MINW > 2) sample_time(j0, ts[0], aw[0]);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        // :457-465 / :477-485 (sums in the reference's order), then the float round trip
-        pos[k] = round_through_float(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
-        vels[j][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
+      for (int c = 0; c < CH; ++c) {
+        const R t = ts[MINW <= 2 ? j0 + c : 0];
+        const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+        const R d2 = (R)2 * t, d3 = K.k3 * t2, d4 = (R)4 * t3, d5 = K.k5 * t4;   // d/dt of the powers
+        R pos[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          // :457-465 / :477-485 (sums in the reference's order), then the float round trip
+          pos[k] = round_through_float(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
+          vels[c][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
+        }
+        taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
       }
-      taps[j] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
-    }
-    GTOP_STAMP(4);   // corner loads issued
-    __builtin_amdgcn_sched_barrier(0);   // every corner load is issued above this line ...
-    // ... and what does not need them runs while they are in flight: the jerk term and the speeds
-    jerk_init();
-    R vns[SPL], ivns[SPL];
+      if (j0 == 0) GTOP_STAMP(4);   // corner loads issued
+      if constexpr (CH == SPL) __builtin_amdgcn_sched_barrier(0);   // every corner load is issued above this line ...
+      // ... and what does not need them runs while they are in flight: the jerk term and the speeds
+      if (j0 == 0) jerk_init();
+      R vns[CH], ivns[CH];
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-      const R *vel = vels[j];
-      vns[j] = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;   // :358
-      ivns[j] = quick_rcp(vns[j]);
-    }
+      for (int c = 0; c < CH; ++c) {
+        const R *vel = vels[c];
+        vns[c] = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + K.eps;   // :358
+        ivns[c] = quick_rcp(vns[c]);
+      }
 #ifdef GTOP_STAMPS
-    asm volatile("" ::"v"(vns[0]), "v"(ivns[SPL - 1]), "v"(acc[18]), "v"(acc[3]));
-    GTOP_STAMP(5);   // in-flight work done
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GTOP_STAMP(6);   // corner loads landed
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    // stage B: trilinear blend, penalty, accumulation
-#pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-      const R t = ts[j];
-      const R *vel = vels[j];
-      const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-      const R vn = vns[j], ivn = ivns[j];
-      R g3[3];
-      bool is_out;
-      const R dist = sdf_blend(taps[j], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
-      const R e = penalty_exp((pen_d0 - dist) * pen_inv_r, expk);   // exp(-(d - d0)/r)
-      const R cdw = aw[j] * e;      // wc*dt * cd, cd of :509 (idle lanes compute on shadow data; never read)
-      const R cv = cdw * vn;
-      acc[18] += cv;                // :373, weighted as in :417-418
-      // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381); gd of :514
-      const R f1 = is_out ? (R)0 : ((pen_gd * a.res_inv) * e) * cv, f2 = cdw * ivn;
-      const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const R w1k = f1 * g3[k], w2k = f2 * vel[k];
-        R *ak = acc + 6 * k;
-        ak[0] += w1k;
-        ak[1] = gfma(w1k, t, ak[1] + w2k);
-        ak[2] = gfma(w1k, t2, gfma(w2k, d2, ak[2]));
-        ak[3] = gfma(w1k, t3, gfma(w2k, d3, ak[3]));
-        ak[4] = gfma(w1k, t4, gfma(w2k, d4, ak[4]));
-        ak[5] = gfma(w1k, t5, gfma(w2k, d5, ak[5]));
+      if (j0 == 0) {
+        asm volatile("" ::"v"(vns[0]), "v"(ivns[CH - 1]), "v"(acc[18]), "v"(acc[3]));
+        GTOP_STAMP(5);   // in-flight work done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GTOP_STAMP(6);   // corner loads landed
       }
+#endif
+      if constexpr (CH == SPL) __builtin_amdgcn_sched_barrier(0);
+      // stage B: trilinear blend, penalty, accumulation
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const R t = ts[MINW <= 2 ? j0 + c : 0];
+        const R *vel = vels[c];
+        const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+        const R vn = vns[c], ivn = ivns[c];
+        R g3[3];
+        bool is_out;
+        const R dist = sdf_blend(taps[c], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
+        const R e = penalty_exp((pen_d0 - dist) * pen_inv_r, expk);   // exp(-(d - d0)/r)
+        const R cdw = aw[MINW <= 2 ? j0 + c : 0] * e;   // wc*dt * cd, cd of :509 (idle lanes: shadow data, never read)
+        const R cv = cdw * vn;
+        acc[18] += cv;                // :373, weighted as in :417-418
+        // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381); gd of :514
+        const R f1 = is_out ? (R)0 : ((pen_gd * a.res_inv) * e) * cv, f2 = cdw * ivn;
+        const R d2 = (R)2 * t, d3 = K.k3 * t2, d4 = (R)4 * t3, d5 = K.k5 * t4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const R w1k = f1 * g3[k], w2k = f2 * vel[k];
+          R *ak = acc + 6 * k;
+          ak[0] += w1k;
+          ak[1] = gfma(w1k, t, ak[1] + w2k);
+          ak[2] = gfma(w1k, t2, gfma(w2k, d2, ak[2]));
+          ak[3] = gfma(w1k, t3, gfma(w2k, d3, ak[3]));
+          ak[4] = gfma(w1k, t4, gfma(w2k, d4, ak[4]));
+          ak[5] = gfma(w1k, t5, gfma(w2k, d5, ak[5]));
+        }
+      }
+      if constexpr (CH != SPL) __builtin_amdgcn_sched_barrier(0);   // keep the samples apart: one sample's corners live
     }
   } else {
     (void)wdt; (void)pen_d0; (void)pen_inv_r; (void)pen_alpha; (void)pen_gd;
@@ -1293,40 +1327,45 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   GTOP_STAMP(7);   // stage B done
 #endif
   // ---- A_s^-T on the lane's 18 accumulators: coefficient space -> [p0,pT,v0,vT,a0,aT] per axis ----
+  R jT3 = iT3, jT4 = iT4, jT5 = iT5;
+  if constexpr (MINW > 2) {   // (three registers fewer to carry across the samples)
+    R iTb = iT;
+    asm volatile("" : "+v"(iTb));
+    jT3 = iTb * iTb * iTb; jT4 = jT3 * iTb; jT5 = jT4 * iTb;
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     R *g = acc + 6 * k;
-    const R H3 = g[3] * iT3, H4 = g[4] * iT4, H5 = g[5] * iT5;
-    const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
+    const R H3 = g[3] * jT3, H4 = g[4] * jT4, H5 = g[5] * jT5;
+    const R ap = K.k10 * H3 - K.k15 * H4 + K.k6 * H5;
     const R o0 = g[0] - ap;
-    const R o2 = g[1] + T * ((R)-6 * H3 + (R)8 * H4 - (R)3 * H5);
-    const R o3 = T * ((R)-4 * H3 + (R)7 * H4 - (R)3 * H5);
-    const R o4 = (R)0.5 * g[2] + T2 * ((R)-1.5 * H3 + (R)1.5 * H4 - (R)0.5 * H5);
+    const R o2 = g[1] + T * (K.k8 * H4 - K.k6 * H3 - K.k3 * H5);
+    const R o3 = T * (K.k7 * H4 - (R)4 * H3 - K.k3 * H5);
+    const R o4 = (R)0.5 * g[2] + T2 * (K.k1p5 * H4 - K.k1p5 * H3 - (R)0.5 * H5);
     const R o5 = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
     g[0] = o0; g[1] = ap; g[2] = o2; g[3] = o3; g[4] = o4; g[5] = o5;
   }
-  // ---- the one LDS round trip: tile[v][lane], then each free variable sums its 2*LPS entries ----
+  // ---- the one LDS round trip: tile[v][lane], then each free variable (and each segment's cost) sums its entries ----
   if (lane < LPS * SPW) {
 #pragma unroll
-    for (int v = 0; v < 18; ++v) tile[v * kStride + lane] = acc[v];   // (columns of idle slots are never read)
+    for (int v = 0; v < kRedVals; ++v) tile[v * kStride + lane] = acc[v];   // (columns of idle slots are never read)
   }
   GTOP_STAMP(8);   // A^-T + tile writes issued
-  // ---- cost (:417-418): every term is already weighted; wavefront sum on the DPP path (no LDS), placed
-  //      between the tile's writes and reads so that it covers the LDS latency ----
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const bool mine = seg_ok & (NT == 1 || tl == t);
-    const R total = wave_sum(mine ? acc[18] : (R)0);
-    if (grp_ok & (lane == 0) & (b0 + t < a.B)) a.cost[b0 + t] = total + (R)1e-3;
-  }
-  GTOP_STAMP(9);   // cost summed and stored
+  GTOP_STAMP(9);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
   __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
+  R cpart = (R)0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
-    const R v = tree_sum<R, LPS>(tile + offA[r]) + tree_sum<R, LPS>(tile + offB[r]);
-    if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = v + (R)1e-5;
+    const R sa = tree_sum<R, LPS>(tile + offA[r]), sb = tree_sum<R, LPS>(tile + offB[r]);
+    if (r == 0 && cost_lane) cpart = sa;
+    if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = (sa + sb) + K.eps;
   }
+  // ---- cost (:417-418): every term is already weighted; lanes 48..53 hold the segment sums ----
+  cpart += gtop_dpp_move<0x111>(cpart);   // row_shr:1
+  cpart += gtop_dpp_move<0x112>(cpart);   // row_shr:2
+  cpart += gtop_dpp_move<0x114>(cpart);   // row_shr:4  -> lane 55 holds lanes 48..55
+  if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
   GTOP_STAMP(10);   // gradient stored (issued)
 #ifdef GTOP_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1376,9 +1415,14 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
       GtopKernelArgs<R> wa = args;
       if (wa.step == 1) wa.ws = (R)0;   // :412-415, applied here so that the kernel need not fetch `step`
       const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
-      hipLaunchKernelGGL((colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false>),
-                         dim3(grid), dim3(64), 18 * red_stride(3) * sizeof(R), stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B,
-                         wa.m, wa.t_stride, wa.nx, wa.ny, wa.nz, wa);
+#ifndef GTOP_WAVE_MINW3_FROM
+#define GTOP_WAVE_MINW3_FROM 3072   // batches that put a third wavefront on a SIMD (1 024 SIMDs)
+#endif
+      auto kern = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2>;
+      if (args.B >= GTOP_WAVE_MINW3_FROM)
+        kern = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 3> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 3>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64), kRedVals * red_stride(3) * sizeof(R), stream, wa.x, wa.Df, wa.T, wa.sdf,
+                         wa.B, wa.m, wa.t_stride, wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{});
       return hipGetLastError();
     }
   }

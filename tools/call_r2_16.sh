@@ -1,0 +1,25 @@
+source tools/gpu_step.sh
+step 600 gpurun_out/pytest16.log python -m pytest tests/test_gpu_parity.py tests/test_gpu_api.py tests/test_analytic.py tests/test_golden.py -q -m gpu -x
+tail -3 gpurun_out/pytest16.log
+for lib in default W0; do
+  for B in 1024 2048 4096; do
+    if [ $lib = default ]; then unset GTOP_HIP_LIB; else export GTOP_HIP_LIB=$PWD/build_var/lib$lib.so; fi
+    step 120 gpurun_out/b_${lib}_$B.json python bench.py --no-extras --no-cpu-baseline --steps 2000 --batch $B
+    python -c "
+import json,sys
+for l in open('gpurun_out/b_${lib}_$B.json'):
+    if l.startswith('{'):
+        d=json.loads(l); print('$lib', $B, '%.3f us' % d['roofline']['avg_launch_us'], 'frac %.3f' % d['roofline']['frac'], 'value %.3e' % d['value'], d['parity']['max_rel_cost'], d['parity']['max_rel_grad'])
+"
+  done
+done
+unset GTOP_HIP_LIB
+for cfg in "--batch 16384 --dtype f64" "--batch 16384 --dtype f64 --spl 3 --waves 1" "--batch 16384 --dtype f32" "--batch 16384 --dtype f32 --spl 3 --waves 1" "--batch 8192 --dtype f64" "--batch 8192 --dtype f64 --spl 3 --waves 1" "--batch 4096 --dtype f32" "--batch 4096 --dtype f32 --spl 3 --waves 1"; do
+  step 120 gpurun_out/b_big.json python bench.py --no-extras --no-cpu-baseline --steps 500 $cfg
+  python -c "
+import json,sys
+for l in open('gpurun_out/b_big.json'):
+    if l.startswith('{'):
+        d=json.loads(l); print('$cfg', '%.3f us' % d['roofline']['avg_launch_us'], 'frac %.3f' % d['roofline']['frac'], d['parity']['ok'])
+"
+done
