@@ -1073,7 +1073,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   constexpr int LPS = kSamples / SPL;   // lanes per segment
   constexpr int SPW = 64 / LPS;         // segment slots per wavefront
   constexpr int kStride = red_stride(SPL);
-  static_assert(SPL <= 3, "samples of a lane are unrolled");
+  static_assert(SPL == 3 || SPL == 6, "10 or 5 lanes per segment");
+  static_assert(SPL == 3 || MINW >= 3, "six samples per lane: one (pair) at a time only");
+  static_assert(NT == 1 || NT == 2, "one or two trajectories per wavefront");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);   // [18][kStride]
   GTOP_STAMP(0);
@@ -1147,13 +1149,17 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     offA[r] = okq[r] ? (rowB + 1) * kStride + sA * LPS : 0;
     offB[r] = okq[r] ? rowB * kStride + (sA + 1) * LPS : 0;
   }
-  // The scalar cost takes the same road: row 18 of the tile holds the lanes' cost accumulators, and lanes 48 .. 48+m-1
-  // (idle in the sum above: n <= 45) each sum one segment's ten with the very instructions the free variables use;
-  // three DPP row shifts then add the (at most six) segment sums.  (A 64-lane DPP sum of the accumulators was 46
-  // instructions of a lone wavefront's issue time.)
-  static_assert(NT == 1 && SPL == 3, "cost lanes 48..53 assume one trajectory of at most 6 segments per wavefront");
-  const bool cost_lane = (lane >= 48) & (lane < 48 + m);
-  if (cost_lane) offA[0] = 18 * kStride + (lane - 48) * LPS;
+  // The scalar cost takes the same road: row 18 of the tile holds the lanes' cost accumulators, and lanes 48 ..
+  // 48 + NT*m - 1 — idle in the LAST round of the sum above (at most 45, 35 or 26 of its lanes carry free variables) —
+  // each sum one segment's entries with the very instructions the free variables use; DPP row shifts then add the
+  // segment sums of a trajectory.  (A 64-lane DPP sum of the accumulators was 46 instructions of a lone wavefront's
+  // issue time.)
+  // NT = 2: trajectory t's segments sit in lanes 48 + 8t .. 48 + 8t + m - 1, so that both trajectories' sums associate
+  // the same way (a trajectory's result must not depend on its place in the pair).
+  const int cs = lane - 48;
+  const int ct = NT == 2 ? cs >> 3 : 0, csi = NT == 2 ? cs & 7 : cs;   // trajectory, segment
+  const bool cost_lane = (cs >= 0) & (csi < m);
+  if (cost_lane) offA[kRounds - 1] = 18 * kStride + (ct * m + csi) * LPS;
   const R ws = a.ws;   // the launcher has applied :412-415 (step 1 -> ws = 0): `step` is not read here
   const R wc = a.wc;
   ExpConsts expk;
@@ -1247,7 +1253,31 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // scheduling barriers.  Throughput regime (MINW = 3): one sample at a time — other wavefronts cover the loads,
     // and only one sample's corners are live (the 168-VGPR budget of a third wavefront).
     constexpr int CH = (MINW <= 2) ? SPL : 1;
+    constexpr int kUnrollJ = SPL <= 3 ? SPL : 1;   // six samples per lane stay a loop (code size)
+    if constexpr (kIsF32<R> && SPL % 2 == 0) {
+      // packed fp32 (see sample_pair_f32): samples jj and jj+1 of this lane together in float2 registers
+      jerk_init();
+      float cq[18];
 #pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cq[6 * k + c] = (float)q[k][c];
+      f2 acc2[kRedVals];
+#pragma unroll
+      for (int v = 0; v < kRedVals; ++v) acc2[v] = (f2){(float)acc[v], 0.0f};
+#pragma unroll 1
+      for (int jj = 0; jj < SPL; jj += 2) {
+        R tA, tB, awA, awB;
+        sample_time(jj, tA, awA);
+        sample_time(jj + 1, tB, awB);
+        sample_pair_f32<false, WIDE>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, (f2){(float)tA, (float)tB},
+                                     awA != (R)0, awB != (R)0, (float)wdt, (float)dt, acc2);
+      }
+#pragma unroll
+      for (int v = 0; v < kRedVals; ++v) acc[v] = (R)(acc2[v].x + acc2[v].y);
+    } else {
+    if constexpr (MINW > 2) jerk_init();
+#pragma unroll kUnrollJ
     for (int j0 = 0; j0 < SPL; j0 += CH) {
       // stage A: positions, index arithmetic, corner loads
       R vels[CH][3];
@@ -1270,7 +1300,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       if (j0 == 0) GTOP_STAMP(4);   // corner loads issued
       if constexpr (CH == SPL) __builtin_amdgcn_sched_barrier(0);   // every corner load is issued above this line ...
       // ... and what does not need them runs while they are in flight: the jerk term and the speeds
-      if (j0 == 0) jerk_init();
+      if constexpr (MINW <= 2) jerk_init();
       R vns[CH], ivns[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
@@ -1318,6 +1348,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       }
       if constexpr (CH != SPL) __builtin_amdgcn_sched_barrier(0);   // keep the samples apart: one sample's corners live
     }
+    }
   } else {
     (void)wdt; (void)pen_d0; (void)pen_inv_r; (void)pen_alpha; (void)pen_gd;
     jerk_init();
@@ -1354,18 +1385,29 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   GTOP_STAMP(9);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
   __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
-  R cpart = (R)0;
+  R csum_seg = (R)0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const R sa = tree_sum<R, LPS>(tile + offA[r]), sb = tree_sum<R, LPS>(tile + offB[r]);
-    if (r == 0 && cost_lane) cpart = sa;
+    if (r == kRounds - 1 && cost_lane) csum_seg = sa;
     if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = (sa + sb) + K.eps;
   }
-  // ---- cost (:417-418): every term is already weighted; lanes 48..53 hold the segment sums ----
-  cpart += gtop_dpp_move<0x111>(cpart);   // row_shr:1
-  cpart += gtop_dpp_move<0x112>(cpart);   // row_shr:2
-  cpart += gtop_dpp_move<0x114>(cpart);   // row_shr:4  -> lane 55 holds lanes 48..55
-  if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
+  // ---- cost (:417-418): every term is already weighted; lanes 48.. hold the segment sums ----
+  {
+    R cpart = cost_lane ? csum_seg : (R)0;
+    cpart += gtop_dpp_move<0x111>(cpart);   // row_shr:1
+    cpart += gtop_dpp_move<0x112>(cpart);   // row_shr:2
+    cpart += gtop_dpp_move<0x114>(cpart);   // row_shr:4  -> lane 55 holds lanes 48..55, lane 63 lanes 56..63
+    if constexpr (NT == 2) {
+      if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
+      if (grp_ok & (lane == 63) & (b0 + 1 < a.B)) a.cost[b0 + 1] = cpart + (R)1e-3;
+    } else if constexpr (SPW > 8) {
+      cpart += gtop_dpp_move<0x118>(cpart);   // row_shr:8 -> lane 63 holds lanes 48..63 (up to 12 segments)
+      if (grp_ok & (lane == 63)) a.cost[b0] = cpart + (R)1e-3;
+    } else {
+      if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
+    }
+  }
   GTOP_STAMP(10);   // gradient stored (issued)
 #ifdef GTOP_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1411,17 +1453,32 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
 #define GTOP_WAVE_KERNEL 1
 #endif
   if constexpr (GTOP_WAVE_KERNEL && !MMA && !DYN) {
-    if (wave_ok && one && spl == 3) {   // one wavefront per trajectory: the barrier-free chain
-      GtopKernelArgs<R> wa = args;
-      if (wa.step == 1) wa.ws = (R)0;   // :412-415, applied here so that the kernel need not fetch `step`
-      const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
+    // gtop_eval_wave_kernel: whole trajectories per wavefront, no workgroup barrier.  spl 3: one trajectory of up to
+    // 6 segments (latency variant below GTOP_WAVE_MINW3_FROM trajectories); spl 6: one trajectory of up to 12 segments,
+    // or two of up to 6 (fp32: packed sample pairs).
 #ifndef GTOP_WAVE_MINW3_FROM
 #define GTOP_WAVE_MINW3_FROM 3072   // batches that put a third wavefront on a SIMD (1 024 SIMDs)
 #endif
-      auto kern = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2>;
+#ifndef GTOP_WAVE_SPL6
+#define GTOP_WAVE_SPL6 1
+#endif
+    constexpr int kW6 = 3;   // register budget of the spl 6 variants: wavefronts per SIMD (fp32 at 4 spills 25 VGPRs)
+    void (*wk)(const R *, const R *, const R *, const R *, int, int, int, int, int, int, const GtopKernelArgs<R>,
+               const GtopWaveConsts<R>) = nullptr;
+    GtopKernelArgs<R> wa = args;
+    if (wa.step == 1) wa.ws = (R)0;   // :412-415, applied here so that the kernel need not fetch `step`
+    const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
+    if (wave_ok && one && spl == 3) {
+      wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2>;
       if (args.B >= GTOP_WAVE_MINW3_FROM)
-        kern = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 3> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 3>;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(64), kRedVals * red_stride(3) * sizeof(R), stream, wa.x, wa.Df, wa.T, wa.sdf,
+        wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 3> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 3>;
+    } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 1) {
+      wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 1, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 1, false, kW6>;
+    } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 2) {
+      wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 2, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 2, false, kW6>;
+    }
+    if (wk) {
+      hipLaunchKernelGGL(wk, dim3(grid), dim3(64), kRedVals * red_stride(spl) * sizeof(R), stream, wa.x, wa.Df, wa.T, wa.sdf,
                          wa.B, wa.m, wa.t_stride, wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{});
       return hipGetLastError();
     }
