@@ -36,7 +36,7 @@ s = buf[:nb, :12].astype(np.int64)
 names = ["wave start -> kernel arguments in SGPRs", "indices, addresses, 13 input loads issued", "inputs landed (wait)",
          "coefficients, sample times, stage A (12 corner loads issued)", "in flight: jerk term, speeds",
          "corner loads landed (wait)", "stage B: blend, penalty, accumulation", "A^-T, tile writes",
-         "cost: DPP sum + store", "tile reads, sums, gradient store issued", "stores acknowledged (wait)"]
+         "(nothing: two stamps back to back = a stamp's own cost)", "tile reads, sums, gradient + cost stores issued", "stores acknowledged (wait)"]
 d = np.diff(s, axis=1)
 print(f"B={B}: median cycles between stamps (lane 0), {nb} wavefronts; each stamp costs ~50-100 cycles itself")
 for i, nme in enumerate(names):
