@@ -124,6 +124,52 @@ esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict
   }
 }
 
+// The same for columns of up to 256 voxels (NCH <= 4 chunks of 64): the ballots stay in scalar registers, what the
+// other chunks contribute to a chunk (their highest occupied voxel below it, their lowest above it) is scalar
+// arithmetic done once per column, and a lane only searches its own chunk's mask (21 -> 18 us at 200^3; what is
+// left is one dependent round trip per wavefront generation — storing the distance as a byte instead of its square
+// as an int made this sweep 2 us faster and the y sweep 2.4 us slower).
+template <int NCH>
+__global__ void __launch_bounds__(256)
+esdf_z_small_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out,
+                    uint8_t *__restrict__ colany) {
+  constexpr int kFar = 1 << 20;   // "no occupied voxel on that side": farther than any column is long
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t ncol = (size_t)g.nx * g.ny;
+  const int nz = g.nz;
+  for (size_t col = (size_t)blockIdx.x * 4 + w; col < ncol; col += (size_t)gridDim.x * 4) {
+    const uint8_t *c = occ + col * nz;
+    unsigned long long mk[NCH];
+    int hi[NCH], lo[NCH];   // highest / lowest occupied voxel of each chunk (scalar)
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int z = k * 64 + lane;
+      mk[k] = __ballot((z < nz) && (c[z] == 1));
+      any |= mk[k];
+      hi[k] = mk[k] ? k * 64 + 63 - __clzll((long long)mk[k]) : -kFar;
+      lo[k] = mk[k] ? k * 64 + (__ffsll((long long)mk[k]) - 1) : kFar;
+    }
+    if (lane == 0) colany[col] = any != 0ull;   // the column holds an obstacle: finite for the y sweep
+#pragma unroll
+    for (int ko = 0; ko < NCH; ++ko) {
+      int below = -kFar, above = kFar;   // nearest occupied voxel in the chunks under / over this one
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        if (k < ko) below = max(below, hi[k]);
+        if (k > ko) above = min(above, lo[k]);
+      }
+      const int z = ko * 64 + lane;
+      const unsigned long long mb = mk[ko] & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));   // bits <= lane
+      const unsigned long long ma = mk[ko] & (~0ull << lane);                                     // bits >= lane
+      const int d1 = mb ? lane - (63 - __clzll((long long)mb)) : kFar;
+      const int d2 = ma ? (__ffsll((long long)ma) - 1) - lane : kFar;
+      const int best = min(min(d1, d2), min(z - below, above - z));
+      if (z < nz) out[col * nz + z] = best >= (kFar >> 1) ? kInf : best * best;
+    }
+  }
+}
+
 // Candidate columns of every row x for the y sweep: cols[x][0..cnt[x]) = the y of the
 // columns that hold an obstacle, ascending; rank[x][y] = number of them below y
 // (= index of the first candidate at or above y).  One wavefront per row.
@@ -368,7 +414,13 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
   int *cols = rows, *rank = rows + ncol, *cnt = rows + 2 * ncol;
   uint8_t *colany = reinterpret_cast<uint8_t *>(rows + 2 * ncol + g.nx);
   const unsigned zblocks = (unsigned)((ncol + 3) / 4 < 65536 ? (ncol + 3) / 4 : 65536);
-  hipLaunchKernelGGL(esdf_z_kernel, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany);
+  switch ((g.nz + 63) >> 6) {
+    case 1: hipLaunchKernelGGL(esdf_z_small_kernel<1>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
+    case 2: hipLaunchKernelGGL(esdf_z_small_kernel<2>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
+    case 3: hipLaunchKernelGGL(esdf_z_small_kernel<3>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
+    case 4: hipLaunchKernelGGL(esdf_z_small_kernel<4>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
+    default: hipLaunchKernelGGL(esdf_z_kernel, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(esdf_rows_kernel, dim3(g.nx < 65536 ? g.nx : 65536), dim3(64), 0, stream, g,
