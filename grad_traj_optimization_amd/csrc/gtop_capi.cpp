@@ -160,15 +160,15 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
 void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb, int auto_spl = 0,
                      bool f32 = false) {
   int s = c->spl;
-  // auto rule (measured): up to 256 trajectories a trajectory is spread over three wavefronts
-  // (latency: one sample per lane); then one wavefront per trajectory, which for m <= 6 is gtop_eval_wave_kernel —
-  // in fp64 at EVERY larger batch (its three-wavefronts-per-SIMD variant beats the two-trajectories-per-wavefront
-  // body up to at least 65 536: 33.8 vs 38.4 us at 16 384), in fp32 up to 8 192, where the packed-fp32
-  // two-trajectory body takes over (22.9 vs 26.0 us at 16 384)
+  // auto rule (measured).  m <= 6: one wavefront per trajectory, gtop_eval_wave_kernel, at EVERY
+  // batch size in fp64 (B = 1: 3.45 us against 4.00 for a trajectory spread over three wavefronts; 16 384: 33.8 against
+  // 38.4 for two trajectories per wavefront) and in fp32 up to 8 192, where the packed-fp32 two-trajectory kernel takes
+  // over (22.3 against 26.0 us at 16 384).  Longer trajectories: three wavefronts' worth of lanes (one sample per lane)
+  // up to 256 of them, then one wavefront pair, from 4 096 one wavefront (six samples per lane).
   if (s == 0) {
     if (auto_spl) s = auto_spl;
-    else if (B <= 256) s = 1;
     else if (m <= 6) s = (f32 && B >= 8192) ? c->auto_spl_large : c->auto_spl_small;
+    else if (B <= 256) s = 1;
     else s = (B >= 4096) ? c->auto_spl_large : c->auto_spl_small;
   }
   const int spw = gtop_eval_segments_per_wave(s);
