@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gtop_device_common.h"
 #include "gtop_kernels.h"
 
@@ -1061,11 +1063,19 @@ struct GtopWaveConsts {
 
 // MINW = wavefronts per SIMD the register budget must leave room for: 2 in the latency regime (constants pinned
 // in VGPRs, 232 of them), 3 for batches that can fill a third (no pins; 168-VGPR budget).
-template <typename R, bool WIDE, int SPL, int NT, bool COLLI, int MINW>
+// MM = GtopMmaState (fp64, NT = 1): the batched CCSA-MMA driver's loop around the evaluation, all st.iters
+// evaluations of the trajectory in this one launch — evaluate at st.xcur, update (gtop_mma_update_trajectory: accept /
+// reject, asymptotes, stop rules, next trial point), evaluate again; cost and gradient never leave the chip.  One
+// wavefront owns the trajectory, so the loop needs no barrier at all.  MM = GtopNoMma: a plain evaluation.
+struct GtopNoMma {};
+
+template <typename R, bool WIDE, int SPL, int NT, bool COLLI, int MINW, typename MM = GtopNoMma>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MINW)))
 gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df, const R *__restrict__ arg_T,
                       const R *__restrict__ arg_sdf, int arg_B, int arg_m, int arg_t_stride, int arg_nx, int arg_ny,
-                      int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K) {
+                      int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K, const MM st) {
+  constexpr bool MMA = !std::is_same<MM, GtopNoMma>::value;
+  static_assert(!MMA || (NT == 1 && sizeof(R) == 8), "the optimizer loop: fp64, one trajectory per wavefront");
   GtopKernelArgs<R> a = arg_rest;
   a.x = arg_x; a.Df = arg_Df; a.T = arg_T; a.sdf = arg_sdf;
   a.B = arg_B; a.m = arg_m; a.t_stride = arg_t_stride;
@@ -1077,7 +1087,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   static_assert(SPL == 3 || MINW >= 3, "six samples per lane: one (pair) at a time only");
   static_assert(NT == 1 || NT == 2, "one or two trajectories per wavefront");
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  R *tile = reinterpret_cast<R *>(smem_raw);   // [18][kStride]
+  R *tile = reinterpret_cast<R *>(smem_raw);   // [19][kStride] (+ [kRounds*64] gradient for the optimizer update)
   GTOP_STAMP(0);
   GTOP_STAMP_HWID();
   const int lane = threadIdx.x;
@@ -1106,9 +1116,28 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   const bool seg_ok = grp_ok & (slot < NT * m) & (b0 + tl < a.B);
   if (!seg_ok) { tl = 0; s = 0; }   // idle lanes shadow the first segment: finite data, results never read
 
+  unsigned long long t_launch = 0ull;
+  int npass = 1;
+  if constexpr (MMA) {
+    t_launch = wall_clock64();
+    npass = st.iters;
+  }
+  for (int pass = 0; pass < npass; ++pass) {
+  const R *xsrc = a.x;
+  if constexpr (MMA) {
+    // stop rules (mma.hpp:35-39; set_maxtime, :144-148), wave-uniform: a trajectory that has stopped (ftol / xtol in the
+    // update) leaves the loop; past the wall-clock limit a running one stops where it is, after at least one evaluation
+    const int stt = __hip_atomic_load(&st.state[b0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!grp_ok || stt >= 3) break;
+    if (st.max_ticks > 0 && pass > 0 && (long long)(wall_clock64() - t_launch) > st.max_ticks) {
+      if (lane == 0) st.state[b0] = GTOP_MMA_MAXTIME_REACHED;
+      break;
+    }
+    xsrc = reinterpret_cast<const R *>(st.xcur);   // (not the __restrict__ argument: the update below rewrites it)
+  }
   // ---- inputs: two waypoints' (p, v, a) per axis and T_s, straight from HBM/L2 ----
   // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
-  const R *xb = a.x + (size_t)b0 * n + tl * n;      // this lane's trajectory (b0: wave-uniform)
+  const R *xb = xsrc + (size_t)b0 * n + tl * n;      // this lane's trajectory (b0: wave-uniform)
   const R *dfb = a.Df + (size_t)b0 * 18 + tl * 18;
   const R T = a.T[(size_t)b0 * a.t_stride + tl * a.t_stride + s];
   // axis 0: the (p, v, a) triple at the segment's start and at its end; the other axes are one per-lane stride
@@ -1166,7 +1195,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   R pen_d0 = a.d0, pen_inv_r = a.inv_r, pen_alpha = a.alpha, pen_gd = -a.alpha_over_r;   // (:507-515)
   MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
                       {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
-  if constexpr (COLLI && !kIsF32<R> && MINW <= 2) {
+  if constexpr (COLLI && !kIsF32<R> && MINW <= 2 && !MMA) {   // (the optimizer loop has no registers to spare)
     expk.pin();
     mapbox.pin();
   }
@@ -1386,11 +1415,16 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
   __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
   R csum_seg = (R)0;
+  R *gl = tile + kRedVals * kStride;   // [kRounds*64]: the gradient for the optimizer update (MMA only)
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const R sa = tree_sum<R, LPS>(tile + offA[r]), sb = tree_sum<R, LPS>(tile + offB[r]);
     if (r == kRounds - 1 && cost_lane) csum_seg = sa;
-    if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = (sa + sb) + K.eps;
+    if constexpr (MMA) {
+      if (okq[r]) gl[lane + 64 * r] = (sa + sb) + K.eps;   // consumed below; nothing leaves the chip
+    } else {
+      if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = (sa + sb) + K.eps;
+    }
   }
   // ---- cost (:417-418): every term is already weighted; lanes 48.. hold the segment sums ----
   {
@@ -1404,6 +1438,17 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     } else if constexpr (SPW > 8) {
       cpart += gtop_dpp_move<0x118>(cpart);   // row_shr:8 -> lane 63 holds lanes 48..63 (up to 12 segments)
       if (grp_ok & (lane == 63)) a.cost[b0] = cpart + (R)1e-3;
+    } else if constexpr (MMA) {
+      // f(xcur) to every lane, then this wavefront's optimizer step for its trajectory
+      const unsigned long long u = __builtin_bit_cast(unsigned long long, (double)(cpart + (R)1e-3));
+      const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 55);
+      const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 55);
+      const double fcur = __builtin_bit_cast(double, ((unsigned long long)hi32 << 32) | lo32);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
+      __builtin_amdgcn_wave_barrier();
+      gtop_mma_update_trajectory(st, b0, n, lane, fcur, reinterpret_cast<const double *>(gl));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is rewritten by the next evaluation
+      __builtin_amdgcn_wave_barrier();
     } else {
       if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
     }
@@ -1413,6 +1458,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   GTOP_STAMP(11);   // stores acknowledged
 #endif
+  }   // pass
 }
 
 }  // namespace
@@ -1452,35 +1498,51 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
 #ifndef GTOP_WAVE_KERNEL
 #define GTOP_WAVE_KERNEL 1
 #endif
-  if constexpr (GTOP_WAVE_KERNEL && !MMA && !DYN) {
-    // gtop_eval_wave_kernel: whole trajectories per wavefront, no workgroup barrier.  spl 3: one trajectory of up to
-    // 6 segments (latency variant below GTOP_WAVE_MINW3_FROM trajectories); spl 6: one trajectory of up to 12 segments,
-    // or two of up to 6 (fp32: packed sample pairs).
 #ifndef GTOP_WAVE_MINW3_FROM
 #define GTOP_WAVE_MINW3_FROM 3072   // batches that put a third wavefront on a SIMD (1 024 SIMDs)
 #endif
 #ifndef GTOP_WAVE_SPL6
 #define GTOP_WAVE_SPL6 1
 #endif
-    constexpr int kW6 = 3;   // register budget of the spl 6 variants: wavefronts per SIMD (fp32 at 4 spills 25 VGPRs)
-    void (*wk)(const R *, const R *, const R *, const R *, int, int, int, int, int, int, const GtopKernelArgs<R>,
-               const GtopWaveConsts<R>) = nullptr;
+  if constexpr (GTOP_WAVE_KERNEL && !DYN) {
+    // gtop_eval_wave_kernel: whole trajectories per wavefront, no workgroup barrier.  spl 3: one trajectory of up to
+    // 6 segments (latency variant below GTOP_WAVE_MINW3_FROM trajectories) — with or without the optimizer loop;
+    // spl 6: one trajectory of up to 12 segments, or two of up to 6 (fp32: packed sample pairs).
+    // wave_ok = false (the optimizer's separate-update mode) keeps a plain evaluation on the body its fused modes
+    // run: the wave kernel exactly where they run it (spl 3, one trajectory per wavefront).
     GtopKernelArgs<R> wa = args;
     if (wa.step == 1) wa.ws = (R)0;   // :412-415, applied here so that the kernel need not fetch `step`
     const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
-    if (wave_ok && one && spl == 3) {
-      wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2>;
-      if (args.B >= GTOP_WAVE_MINW3_FROM)
-        wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 3> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 3>;
-    } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 1) {
-      wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 1, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 1, false, kW6>;
-    } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 2) {
-      wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 2, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 2, false, kW6>;
-    }
-    if (wk) {
-      hipLaunchKernelGGL(wk, dim3(grid), dim3(64), kRedVals * red_stride(spl) * sizeof(R), stream, wa.x, wa.Df, wa.T, wa.sdf,
-                         wa.B, wa.m, wa.t_stride, wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{});
-      return hipGetLastError();
+    const bool three = args.B >= GTOP_WAVE_MINW3_FROM;
+    const size_t wsmem = (kRedVals * red_stride(spl) + 128) * sizeof(R);   // tile + the optimizer's gradient rows
+    if constexpr (MMA) {
+      if constexpr (sizeof(R) == 8) {
+        if (one && spl == 3) {
+          // (two wavefronts per SIMD at every batch size: the update's working set spills a 168-VGPR budget)
+          auto wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2, GtopMmaState>
+                          : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2, GtopMmaState>;
+          hipLaunchKernelGGL(wk, dim3(grid), dim3(64), wsmem, stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B, wa.m, wa.t_stride,
+                             wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{}, st);
+          return hipGetLastError();
+        }
+      }
+    } else {
+      constexpr int kW6 = 3;   // register budget of the spl 6 variants: wavefronts per SIMD (fp32 at 4 spills 25 VGPRs)
+      void (*wk)(const R *, const R *, const R *, const R *, int, int, int, int, int, int, const GtopKernelArgs<R>,
+                 const GtopWaveConsts<R>, const GtopNoMma) = nullptr;
+      if (one && spl == 3) {
+        wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2>;
+        if (three) wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 3> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 3>;
+      } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 1) {
+        wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 1, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 1, false, kW6>;
+      } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 2) {
+        wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 2, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 2, false, kW6>;
+      }
+      if (wk) {
+        hipLaunchKernelGGL(wk, dim3(grid), dim3(64), wsmem, stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B, wa.m, wa.t_stride,
+                           wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{}, GtopNoMma{});
+        return hipGetLastError();
+      }
     }
   }
   if constexpr (MMA) {   // the fused optimizer step is built for the geometries the auto rules pick
