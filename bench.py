@@ -304,12 +304,12 @@ def main():
         run_bucket(b)
     if not short:
         ev1.record(stream)
+    drain()                    # the stream now also waits for the last bucket's all-gather (no host wait yet)
     while not stream.query():  # poll: a blocking wait sleeps on an interrupt, tens of us after the last kernel ends
         pass
-    drain()
     torch.cuda.synchronize()
+    t1 = time.perf_counter()   # this rank's K steps and their collectives are done; the job's time is the MAX over ranks
     barrier()
-    t1 = time.perf_counter()
     elapsed = t1 - t0
     if short:
         kern_ms = elapsed * 1e3 / args.steps          # host clock: launch call and completion poll included

@@ -84,7 +84,8 @@ def test_bench_starts_its_own_ranks_and_relays_their_exit_code():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
                          capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode != 0
-    assert "torch.distributed.run" in out.stderr and out.stderr.count("bench.py needs a GPU") == 2
+    # (torchrun may stop the second rank as soon as the first has failed: at least one of them got to say it)
+    assert "torch.distributed.run" in out.stderr and out.stderr.count("bench.py needs a GPU") >= 1
 
 
 def test_shard_range_partitions_exactly():
