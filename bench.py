@@ -278,11 +278,14 @@ def main():
 
     # ---- graph upload: the first replay of an instantiated graph pays a one-time cost (about 25 us here).  It is
     #      part of building the launch plan, like the capture itself, and is reported as such; it is not a step.
+    #      It goes through the pipeline, so the first all-gather of each ring buffer (RCCL sets its channels up
+    #      lazily, hundreds of ms) is paid here too, not inside the timed region of a short run.
     upload_replays = 0
-    if graphs is not None:
+    if graphs is not None or collective:
         for j in range(2):
-            graphs[j].replay()
+            run_bucket(j)
             upload_replays += 1
+        drain()
         torch.cuda.synchronize()
 
     # ---- warmup: exactly W steps (whole buckets through the timed path, the rest as single launches) ----
