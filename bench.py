@@ -253,21 +253,43 @@ def main():
     pipe = ResultGatherPipeline(world, rank, G, hi - lo, tdtype, dev, run_bucket_eager,
                                 n_free=n, gather_grads=args.gather_grads, collective=collective)
     launch_mode = "eager"
+    gather_mode = "none" if not collective else "host call per bucket, overlapped with the next bucket"
     if not args.no_graph:
-        try:
-            graphs = []
+        def capture(with_gather):
+            gs = []
             for j in range(2):
                 gph = torch.cuda.CUDAGraph()
                 # thread_local: a HIP call from another thread (RCCL's watchdog) must not break the capture
                 with torch.cuda.graph(gph, capture_error_mode="thread_local"):
                     run_bucket_eager(j)
-                graphs.append(gph)
-            pipe.run_bucket_fn = run_bucket_graph
-            launch_mode = "hipgraph"
-        except Exception as e:   # capture unsupported: fall back to eager launches, say so
-            print(f"bench.py: graph capture failed ({e}); using eager launches", file=sys.stderr)
-            graphs = None
-            torch.cuda.synchronize()
+                    if with_gather:
+                        pipe.gather_now(j)
+                gs.append(gph)
+            return gs
+        # with a collective (RCCL only): first try to capture the bucket's all-gather INTO its graph, behind the last
+        # kernel — one graph launch per bucket and no collective call from the host (which costs ~50 us exposed per
+        # short timed region); if RCCL cannot be captured here, fall back to graphs of kernels + host-side gathers
+        attempts = ([True] if (collective and backend == "nccl" and os.environ.get("GTOP_BENCH_CAPTURE_GATHER", "1") == "1")
+                    else []) + [False]
+        for with_gather in attempts:
+            try:
+                if with_gather:     # the communicator must exist (and have run once) before it is captured
+                    pipe.gather_now(0)
+                    pipe.gather_now(1)
+                    torch.cuda.synchronize()
+                graphs = capture(with_gather)
+                pipe.run_bucket_fn = run_bucket_graph
+                pipe.gather_in_bucket_fn = with_gather
+                launch_mode = "hipgraph"
+                if with_gather:
+                    gather_mode = "captured in each bucket's hipGraph"
+                break
+            except Exception as e:   # capture unsupported: fall back, say so
+                print(f"bench.py: graph capture {'with the all-gather ' if with_gather else ''}failed ({e})", file=sys.stderr)
+                graphs = None
+                torch.cuda.synchronize()
+        if graphs is None:
+            print("bench.py: using eager launches", file=sys.stderr)
     if rank == 0:
         log(f"launch mode {launch_mode}, {G} steps per bucket, backend {backend if collective else 'none'}")
     run_bucket, drain = pipe.run_bucket, pipe.drain
@@ -394,6 +416,7 @@ def main():
                 "params": "opti_node.launch (ws=1, wc=5, alpha=10, d0=0.8, r=0.5), step=2",
                 "parallelism": par,
                 "launch": launch_mode, "steps_per_bucket": G, "graph_upload_replays": upload_replays,
+                "gather": gather_mode,
                 "collective_bytes_per_bucket": (world * G * (hi - lo) * elem
                                                 + (world * (hi - lo) * n * elem if args.gather_grads else 0))
                                                if collective else 0,

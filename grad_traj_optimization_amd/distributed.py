@@ -54,6 +54,9 @@ class ResultGatherPipeline:
         self.grad_gathered = ([torch.zeros(world_size * local_batch, n_free, dtype=dtype, device=device)
                                for _ in range(2)] if self.gather_grads else None)
         self._pending = [[], []]
+        # True when run_bucket_fn enqueues the all-gathers itself (captured into the bucket's hipGraph behind its last
+        # kernel: one graph launch per bucket, no collective call from the host)
+        self.gather_in_bucket_fn = False
 
     def _gather(self, out, src):
         if self._staged:
@@ -73,10 +76,16 @@ class ResultGatherPipeline:
         j = b & 1
         self._wait(j)                       # ring j is about to be overwritten
         self.run_bucket_fn(j)
-        if self.collective:
+        if self.collective and not self.gather_in_bucket_fn:
             self._pending[j].append(self._gather(self.gathered[j], self.cost_ring[j]))
             if self.gather_grads:
                 self._pending[j].append(self._gather(self.grad_gathered[j], self.grad_ring[j]))
+
+    def gather_now(self, j):
+        """The bucket's all-gathers, synchronously on the current stream (for capture into the bucket's graph)."""
+        dist.all_gather_into_tensor(self.gathered[j], self.cost_ring[j])
+        if self.gather_grads:
+            dist.all_gather_into_tensor(self.grad_gathered[j], self.grad_ring[j])
 
     def drain(self):
         for j in range(2):

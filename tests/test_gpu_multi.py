@@ -37,6 +37,16 @@ def test_bench_rank_path_with_rccl_at_world_size_one():
     assert r["config"]["launch"] == "hipgraph" and r["config"]["steps_per_bucket"] == 10
     assert r["config"]["collective_bytes_per_bucket"] == 10 * 1024 * 8 + 1024 * 45 * 8
     assert r["parity"]["ok"] and r["value"] > 1e4
+    assert r["config"]["gather"] == "captured in each bucket's hipGraph"
+
+
+@pytest.mark.timeout(900)
+def test_bench_rank_path_with_host_side_gathers():
+    # the fallback when RCCL cannot be captured: graphs of kernels, one async all-gather call per bucket
+    r = _bench(["--gpus", "1", "--steps", "40", "--warmup", "7", "--bucket", "10", "--gather-grads",
+                "--no-extras", "--no-cpu-baseline"], {"GTOP_BENCH_FORCE_DIST": "1", "GTOP_BENCH_CAPTURE_GATHER": "0"})
+    assert r["config"]["launch"] == "hipgraph" and r["config"]["gather"].startswith("host call per bucket")
+    assert r["parity"]["ok"] and r["value"] > 1e4
 
 
 @pytest.mark.timeout(900)
