@@ -17,8 +17,9 @@
 //             clz/ctz, no search loop;
 //   y sweep : after the z sweep a voxel of line (x, ., z) is finite exactly when its
 //             (x,y) column holds an obstacle, whatever z — so every row x has ONE
-//             sorted list of candidate columns (built by esdf_rows_kernel with
-//             ballots/popcounts).  A voxel walks that list outward from its own y,
+//             sorted list of candidate columns (ballots/popcounts over the z sweep's
+//             per-column flags: by the y sweep's workgroup itself, in LDS, or by
+//             esdf_rows_kernel for ny > 2048).  A voxel walks that list outward from its own y,
 //             four candidates per round trip, with the exact cut-off d^2 >= best;
 //             obstacle-free stretches cost nothing;
 //   x sweep : outward scan v = q-1, q+1, q-2, ... with the same cut-off (in(v) >= 0);
@@ -32,8 +33,12 @@
 //     slabs as well and one outward pass serves all four (106 -> 65 us), and the yz plane is partitioned over
 //     the 8 XCDs so that those re-reads hit one L2 instead of crossing the fabric (400^3: 1.44 -> 0.96 ms
 //     before the blocking; 0.45 ms with it);
-//   * what is left in the x sweep is its integer min-plus arithmetic (3 instructions per two candidates).
-// Result: bit-identical to the CPU restatement and to scipy's exact EDT (tests), no scratch workspace.
+//   * the x sweep's min-plus arithmetic runs on packed 16-bit values where they fit (esdf_x16_kernel: two voxels
+//     per v_pk_add_u16 / v_pk_min_u16, 8 voxels per 16-byte load; the 32-bit scan is its exact fallback);
+//   * a SIMD's wavefronts share its issue slots, so the x sweep ends when the SIMD with the longest scans does:
+//     the plane is dealt to the XCDs in 64-lane chunks (not one contiguous eighth each) so that each gets an
+//     even sample of the map (65 -> 56 us at 200^3; per-wavefront timeline: tools/esdf_stamps.py).
+// Result: bit-identical to the CPU restatement and to scipy's exact EDT (tests).
 // Rejected with measurements: an LDS-tiled variant of the scans (4-6x slower, round 1); the reference's own
 // lower-envelope algorithm with one lane per line and the stack in LDS (155 us for the x sweep at 200^3, 2.8 ms
 // at 400^3: a line's pops diverge across the 64 lanes and 4 B x line length of LDS per lane leaves one
@@ -207,10 +212,16 @@ __device__ __forceinline__ IntV<V> load_v(const int *p) { return *reinterpret_ca
 
 // y sweep (sdf_map.cpp:328-346): out(x,y,z) = min over candidate columns v of (y-v)^2 + in(x,v,z).
 // 32-bit index arithmetic throughout (nvox < 2^31; ny, nz < 2^15 so that v*nz is a 24-bit product).
-template <int V>
+// LOCAL: the workgroup builds its slab's candidate list itself, in LDS, from the z sweep's per-column flags (ny <=
+// kYLocalMax) — no esdf_rows_kernel launch between the sweeps (5 us of a 110 us build at 200^3), and the list is
+// then read from LDS instead of global memory.
+constexpr int kYLocalMax = 2048;
+
+template <int V, bool LOCAL>
 __global__ void __launch_bounds__(256)
-esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ fout, const int *__restrict__ cols,
-              const int *__restrict__ rank, const int *__restrict__ cnt) {
+esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ fout, uint16_t *__restrict__ fout16,
+              const int *__restrict__ cols, const int *__restrict__ rank, const int *__restrict__ cnt,
+              const uint8_t *__restrict__ colany) {
   constexpr int U = 4;   // candidates per round trip and side
   const int nyz = g.ny * g.nz;
   const int ny = g.ny, nz = g.nz;
@@ -221,26 +232,72 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int x = xcd + 8 * (j / bps);
   const int r = ((j % bps) * 256 + (int)threadIdx.x) * V;
-  if (x >= g.nx || r >= nyz) return;
+  __shared__ unsigned short s_cols[LOCAL ? kYLocalMax : 1];
+  __shared__ unsigned long long s_mask[LOCAL ? kYLocalMax / 64 : 1];
+  __shared__ int s_pref[LOCAL ? kYLocalMax / 64 + 1 : 1];
+  if constexpr (LOCAL) {
+    if (x >= g.nx) return;   // (workgroup-uniform)
+    if (threadIdx.x < 64) {  // one wavefront: ballots over the slab's column flags, 64 columns at a time
+      const int lane = threadIdx.x;
+      const uint8_t *ca = colany + x * ny;
+      constexpr int kPre = 4;   // flag loads in flight
+      int base = 0;
+      for (int y0 = 0; y0 < ny; y0 += 64 * kPre) {
+        bool f[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+          const int y = y0 + 64 * u + lane;
+          f[u] = (y < ny) && ca[y];
+        }
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+          const int y = y0 + 64 * u + lane;
+          if (y0 + 64 * u >= ny) break;
+          const unsigned long long mk = __ballot(f[u]);
+          if (f[u]) s_cols[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)y;
+          if (lane == 0) {
+            s_mask[(y0 >> 6) + u] = mk;
+            s_pref[(y0 >> 6) + u] = base;
+          }
+          base += __popcll(mk);
+        }
+      }
+      if (lane == 0) s_pref[(ny + 63) >> 6] = base;
+    }
+    __syncthreads();
+    if (r >= nyz) return;
+  } else {
+    if (x >= g.nx || r >= nyz) return;
+  }
   const int i = x * nyz + r;
   const int q = r / nz;                   // (nz % V == 0: the V voxels share q)
   const int *line = fin + (i - q * nz);   // (x, 0, z)
-  const int *cx = cols + x * ny;
-  const int c = cnt[x];
+  // the slab's candidate columns, ascending; c of them; k0 = the first at or above q
+  auto cx = [&](int k) -> int {
+    if constexpr (LOCAL) return s_cols[k];
+    else return cols[x * ny + k];
+  };
+  int c, k0;
+  if constexpr (LOCAL) {
+    c = s_pref[(ny + 63) >> 6];
+    k0 = s_pref[q >> 6] + __popcll(s_mask[q >> 6] & ((1ull << (q & 63)) - 1ull));
+  } else {
+    c = cnt[x];
+    k0 = rank[x * ny + q];
+  }
   IntV<V> best = load_v<V>(fin + i);
   int worst = best.v[0];
 #pragma unroll
   for (int e = 1; e < V; ++e) worst = max(worst, best.v[e]);
-  const int k0 = rank[x * ny + q];        // first candidate at or above q
   // below q: candidates k0-1, k0-2, ... (descending y, ascending distance).  Indices are clamped to the
   // list's first entry instead of masked: a re-read candidate cannot beat itself.
   for (int k = k0 - 1; k >= 0; k -= U) {
-    const int d0 = q - cx[k];
+    const int d0 = q - cx(k);
     if (__mul24(d0, d0) >= worst) break;   // in(v) >= 0: nothing farther can win
     int v[U];
     IntV<V> f[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = cx[max(k - u, 0)];
+    for (int u = 0; u < U; ++u) v[u] = cx(max(k - u, 0));
 #pragma unroll
     for (int u = 0; u < U; ++u) f[u] = load_v<V>(line + __mul24(v[u], nz));
 #pragma unroll
@@ -254,13 +311,13 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
     for (int e = 1; e < V; ++e) worst = max(worst, best.v[e]);
   }
   // above q (the voxel's own column, if it is a candidate, is `best` already)
-  for (int k = k0 + ((k0 < c && cx[k0] == q) ? 1 : 0); k < c; k += U) {
-    const int d0 = cx[k] - q;
+  for (int k = k0 + ((k0 < c && cx(k0) == q) ? 1 : 0); k < c; k += U) {
+    const int d0 = cx(k) - q;
     if (__mul24(d0, d0) >= worst) break;
     int v[U];
     IntV<V> f[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = cx[min(k + u, c - 1)];
+    for (int u = 0; u < U; ++u) v[u] = cx(min(k + u, c - 1));
 #pragma unroll
     for (int u = 0; u < U; ++u) f[u] = load_v<V>(line + __mul24(v[u], nz));
 #pragma unroll
@@ -276,6 +333,14 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
 #pragma unroll
   for (int e = 0; e < V; ++e) best.v[e] = best.v[e] > kInf ? kInf : best.v[e];
   *reinterpret_cast<IntV<V> *>(fout + i) = best;
+  if constexpr (V == 4) {
+    if (fout16) {   // the x sweep's packed 16-bit form: min(value, 0xFFFF) (wave-uniform branch)
+      uint2 pk;
+      pk.x = (unsigned)min(best.v[0], 0xFFFF) | ((unsigned)min(best.v[1], 0xFFFF) << 16);
+      pk.y = (unsigned)min(best.v[2], 0xFFFF) | ((unsigned)min(best.v[3], 0xFFFF) << 16);
+      *reinterpret_cast<uint2 *>(fout16 + i) = pk;
+    }
+  }
 }
 
 // x sweep (sdf_map.cpp:348-364): out(q) = min_v ((q-v)^2 + in(v)), scanning outward; then
@@ -291,23 +356,13 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
 #endif
 constexpr int kXB = GTOP_ESDF_XB;
 
+// the scan of one lane's block: V voxels from `first` (slab 0) times the kXB slabs from q0
 template <int V>
-__global__ void __launch_bounds__(256)
-esdf_x_kernel(const GtopGrid g, const int *__restrict__ fin, double *__restrict__ dist, float *__restrict__ dist32) {
+__device__ __forceinline__ void esdf_x_scan_block(const GtopGrid &g, const int *__restrict__ fin, double *__restrict__ dist,
+                                                  float *__restrict__ dist32, const int first, const int q0) {
   constexpr int kScanBatch = 4;   // steps per round trip
   const int nyz = g.ny * g.nz;
   const int n = g.nx;
-  // XCD-aware order: the yz plane is cut in 8 parts and XCD c scans part c of every slab block, block after block —
-  // the rows a lane reads are then shared, in one L2, with the lanes of the neighbouring slab blocks that run at
-  // the same time (dealt linearly, every XCD walked every slab: 1.44 ms -> 0.96 ms at 400^3 with this order).
-  // grid = 8 * ceil(n/kXB) * bpp workgroups, bpp = workgroups per part = ceil(ceil(nyz/V/8)/256).
-  const int nl = nyz / V;
-  const int bpp = (((nl + 7) >> 3) + 255) >> 8, part = bpp << 8;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int q0 = (j / bpp) * kXB;
-  const int fl = xcd * part + (j % bpp) * 256 + (int)threadIdx.x;
-  if (fl >= nl || fl >= (xcd + 1) * part) return;
-  const int first = fl * V;                 // the line (y,z) = its voxel in slab 0
   const int last = first + (n - 1) * nyz;   // the line's end voxels: first, last
   // the block's own rows (slabs past the end of the line shadow the last one; they are not stored)
   int row[kXB];
@@ -385,7 +440,203 @@ esdf_x_kernel(const GtopGrid g, const int *__restrict__ fin, double *__restrict_
   }
 }
 
+#ifdef GTOP_ESDF_STAMPS
+// tuning aid (tools/esdf_stamps.py): per wavefront of the x sweep, start / end on the 100 MHz wall clock, scan
+// steps and placement.  Not part of the product build.
+__device__ unsigned long long g_esdf_stamps[4 * 65536];
+__device__ __forceinline__ void esdf_stamp(unsigned long long t0, int steps) {
+  const unsigned long long t1 = wall_clock64();
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w < 65536) {
+      g_esdf_stamps[4 * w + 0] = t0;
+      g_esdf_stamps[4 * w + 1] = t1;
+      g_esdf_stamps[4 * w + 2] = (unsigned long long)steps;
+      g_esdf_stamps[4 * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4 /* HW_ID, bits 15:0 */) |
+                                 ((unsigned long long)__smid() << 32);
+    }
+  }
+}
+#endif
+
+// XCD-aware order of the x sweep's work: a lane of the yz plane belongs to ONE XCD for every slab block, block
+// after block — the rows a lane reads are then shared, in one L2, with the lanes of the neighbouring slab blocks
+// that run at the same time (dealt linearly, every XCD walked every slab: 1.44 ms -> 0.96 ms at 400^3 with this
+// order).  grid = 8 * ceil(n/kXB) * bpp workgroups, bpp = workgroups per XCD and slab block, nl = lanes per slab
+// block.  Returns false for a lane without work.
+template <int BLOCK = 256>
+__device__ __forceinline__ bool esdf_x_lane(const int nl, int *fl, int *q0) {
+#ifdef GTOP_ESDF_X_PARTS   // round 2's first form: XCD c owns the c-th eighth of the plane (one contiguous part)
+  const int part = (nl + 7) >> 3, bpp = (part + BLOCK - 1) / BLOCK;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int li = (j % bpp) * BLOCK + (int)threadIdx.x;
+  *q0 = (j / bpp) * kXB;
+  *fl = xcd * part + li;
+  return li < part && *fl < nl;
+#else
+  // 64-lane chunks of the plane dealt round-robin over the XCDs: the same lanes of every slab block still meet in
+  // one L2, and every XCD gets an even sample of the map (with one contiguous eighth each, the XCD that owned the
+  // most open space finished 10 us after the others at 200^3)
+  const int cpx = (((nl + 63) >> 6) + 7) >> 3, bpp = (cpx * 64 + BLOCK - 1) / BLOCK;   // chunks, workgroups per XCD
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int li = (j % bpp) * BLOCK + (int)threadIdx.x;
+  *q0 = (j / bpp) * kXB;
+  *fl = (((li >> 6) << 3) + xcd) * 64 + (li & 63);
+  return (li >> 6) < cpx && *fl < nl;
+#endif
+}
+
+template <int V>
+__global__ void __launch_bounds__(256)
+esdf_x_kernel(const GtopGrid g, const int *__restrict__ fin, double *__restrict__ dist, float *__restrict__ dist32) {
+  int fl, q0;
+#ifdef GTOP_ESDF_STAMPS
+  const unsigned long long t0 = wall_clock64();
+#endif
+  if (!esdf_x_lane(g.ny * g.nz / V, &fl, &q0)) return;
+  esdf_x_scan_block<V>(g, fin, dist, dist32, fl * V, q0);
+#ifdef GTOP_ESDF_STAMPS
+  esdf_stamp(t0, -1);
+#endif
+}
+
+// The x sweep on packed 16-bit values.  Squared distances below 2^16 (255 voxels: 51 m at the reference's 0.2 m)
+// fit 16 bits, and the min-plus step on two voxels is then ONE v_pk_add_u16 (saturating) + ONE v_pk_min_u16 —
+// a third of the 32-bit form's instructions per candidate — and a 16-byte load brings 8 voxels.  The y sweep
+// leaves min(value, 0xFFFF) beside its int32 output; a lane owns 8 voxels along z times kXB slabs.  The packed scan
+// returns min(exact, 0xFFFF) for every voxel whatever the inputs: a saturated candidate (>= 0xFFFF, d^2 clamped
+// likewise) can never beat a minimum below 0xFFFF and unsaturated ones are exact.  A wavefront that ends with a
+// saturated minimum (more than 255 voxels of free space, a line without obstacles) takes the 32-bit scan above for
+// its voxels instead.
+typedef unsigned short gtop_u16x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(16))) PkV { gtop_u16x2 p[4]; };
+
+#ifndef GTOP_ESDF_X16_BLOCK
+#define GTOP_ESDF_X16_BLOCK 128
+#endif
+#ifndef GTOP_ESDF_X16_BATCH
+#define GTOP_ESDF_X16_BATCH 4
+#endif
+constexpr int kX16Block = GTOP_ESDF_X16_BLOCK;
+
+__global__ void __launch_bounds__(kX16Block)
+#ifdef GTOP_ESDF_X16_WPE
+__attribute__((amdgpu_waves_per_eu(GTOP_ESDF_X16_WPE)))
+#endif
+esdf_x16_kernel(const GtopGrid g, const uint16_t *__restrict__ f16, const int *__restrict__ fin,
+                double *__restrict__ dist, float *__restrict__ dist32) {
+  constexpr int kScanBatch = GTOP_ESDF_X16_BATCH;
+  const int nyz = g.ny * g.nz;
+  const int n = g.nx;
+  int fl, q0;
+#ifdef GTOP_ESDF_STAMPS
+  const unsigned long long t0 = wall_clock64();
+#endif
+  if (!esdf_x_lane<kX16Block>(nyz >> 3, &fl, &q0)) return;
+  const int first = fl << 3;
+  const int last = first + (n - 1) * nyz;
+  int row[kXB];
+  PkV best[kXB];
+#pragma unroll
+  for (int e = 0; e < kXB; ++e) {
+    row[e] = first + min(q0 + e, n - 1) * nyz;
+    best[e] = *reinterpret_cast<const PkV *>(f16 + row[e]);
+  }
+  auto worst_of = [&]() {
+    gtop_u16x2 w = best[0].p[0];
+#pragma unroll
+    for (int e = 0; e < kXB; ++e)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) w = __builtin_elementwise_max(w, best[e].p[p]);
+    return max((int)w.x, (int)w.y);
+  };
+  auto splat = [](int d) {   // d^2, clamped, in both halves (d is wave-uniform: scalar unit)
+    const unsigned d2 = (unsigned)min(d * d, 0xFFFF);
+    gtop_u16x2 r;
+    r.x = (unsigned short)d2;
+    r.y = (unsigned short)d2;
+    return r;
+  };
+  {
+    PkV own[kXB];
+#pragma unroll
+    for (int e = 0; e < kXB; ++e) own[e] = best[e];
+#pragma unroll
+    for (int e = 0; e < kXB; ++e)
+#pragma unroll
+      for (int o = 0; o < kXB; ++o)
+        if (o != e) {
+          const gtop_u16x2 dd = splat(e - o);
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            best[e].p[p] = __builtin_elementwise_min(best[e].p[p], __builtin_elementwise_add_sat(own[o].p[p], dd));
+        }
+  }
+  int worst = worst_of();
+  const int reach = max(max(q0, n - kXB - q0), 0);
+  int lo = row[0], hi = row[kXB - 1], d = 0;
+  while (d < reach) {
+    if (__mul24(d + 1, d + 1) >= worst) break;
+    PkV flo[kScanBatch], fhi[kScanBatch];
+#pragma unroll
+    for (int u = 0; u < kScanBatch; ++u) {
+      lo = max(lo - nyz, first);
+      hi = min(hi + nyz, last);
+      flo[u] = *reinterpret_cast<const PkV *>(f16 + lo);
+      fhi[u] = *reinterpret_cast<const PkV *>(f16 + hi);
+    }
+#pragma unroll
+    for (int u = 0; u < kScanBatch; ++u) {
+      ++d;
+#pragma unroll
+      for (int e = 0; e < kXB; ++e) {
+        const gtop_u16x2 sl = splat(d + e), sr = splat(d + (kXB - 1 - e));
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          best[e].p[p] = __builtin_elementwise_min(
+              best[e].p[p], __builtin_elementwise_min(__builtin_elementwise_add_sat(flo[u].p[p], sl),
+                                                      __builtin_elementwise_add_sat(fhi[u].p[p], sr)));
+      }
+    }
+    worst = worst_of();
+  }
+  if (__any(worst == 0xFFFF)) {   // (wave-uniform) a minimum at or past 2^16 - 1: the exact 32-bit scan instead
+    esdf_x_scan_block<4>(g, fin, dist, dist32, first, q0);
+    esdf_x_scan_block<4>(g, fin, dist, dist32, first + 4, q0);
+    return;
+  }
+#ifdef GTOP_ESDF_STAMPS
+  const int steps_done = d;
+#endif
+  // every value is below 0xFFFF here: res*sqrt(.) <= 256*res, below the 10000 of sdf_map.cpp:355-361 for any
+  // resolution under 39 m — the min with 10000 is kept for the letter of it
+#pragma unroll
+  for (int e = 0; e < kXB; ++e) {
+    if (q0 + e >= n) break;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int nn[2] = {(int)best[e].p[p].x, (int)best[e].p[p].y};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double r = g.res * sqrt((double)nn[h]);
+        const double dv = r < 10000.0 ? r : 10000.0;
+        dist[row[e] + 2 * p + h] = dv;
+        if (dist32) dist32[row[e] + 2 * p + h] = (float)dv;
+      }
+    }
+  }
+#ifdef GTOP_ESDF_STAMPS
+  esdf_stamp(t0, steps_done);
+#endif
+}
+
 }  // namespace
+
+#ifdef GTOP_ESDF_STAMPS
+extern "C" int gtop_debug_esdf_stamps(unsigned long long *out, size_t n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_esdf_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 hipError_t gtop_launch_esdf_reset(uint8_t *occ, double *dist, size_t nvox, hipStream_t stream) {
   hipLaunchKernelGGL(esdf_reset_kernel, dim3(2048), dim3(256), 0, stream, occ, dist, nvox);
@@ -405,7 +656,9 @@ bool gtop_esdf_supported(const GtopGrid &g) {
 
 size_t gtop_esdf_rows_ints(const GtopGrid &g) {
   const size_t ncol = (size_t)g.nx * g.ny;
-  return 2 * ncol + (size_t)g.nx + (ncol + 3) / 4;   // cols, rank, cnt, colany (bytes)
+  const size_t nvox = ncol * (size_t)g.nz;
+  // cols, rank, cnt, colany (bytes), padding to 16 bytes, the y sweep's 16-bit output
+  return ((2 * ncol + (size_t)g.nx + (ncol + 3) / 4 + 3) & ~(size_t)3) + (nvox + 1) / 2;
 }
 
 hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,
@@ -413,6 +666,7 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
   const size_t ncol = (size_t)g.nx * g.ny;
   int *cols = rows, *rank = rows + ncol, *cnt = rows + 2 * ncol;
   uint8_t *colany = reinterpret_cast<uint8_t *>(rows + 2 * ncol + g.nx);
+  uint16_t *f16 = reinterpret_cast<uint16_t *>(rows + ((2 * ncol + (size_t)g.nx + (ncol + 3) / 4 + 3) & ~(size_t)3));
   const unsigned zblocks = (unsigned)((ncol + 3) / 4 < 65536 ? (ncol + 3) / 4 : 65536);
   switch ((g.nz + 63) >> 6) {
     case 1: hipLaunchKernelGGL(esdf_z_small_kernel<1>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
@@ -423,10 +677,16 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(esdf_rows_kernel, dim3(g.nx < 65536 ? g.nx : 65536), dim3(64), 0, stream, g,
-                     (const uint8_t *)colany, cols, rank, cnt);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
+#ifndef GTOP_ESDF_YLOCAL
+#define GTOP_ESDF_YLOCAL 1
+#endif
+  const bool ylocal = GTOP_ESDF_YLOCAL && g.ny <= kYLocalMax;   // the y sweep lists its slab's candidates itself
+  if (!ylocal) {
+    hipLaunchKernelGGL(esdf_rows_kernel, dim3(g.nx < 65536 ? g.nx : 65536), dim3(64), 0, stream, g,
+                       (const uint8_t *)colany, cols, rank, cnt);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   const int nyz = g.ny * g.nz;
 #ifndef GTOP_ESDF_VEC
 #define GTOP_ESDF_VEC 4
@@ -434,16 +694,37 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
   const int V = (GTOP_ESDF_VEC == 4 && g.nz % 4 == 0) ? 4 : 1;   // voxels per lane (16-byte loads need nz % 4 == 0)
   const int nl = nyz / V;
   const unsigned yblocks = 8u * (unsigned)((g.nx + 7) / 8) * (unsigned)((nl + 255) / 256);
-  const unsigned xblocks = 8u * (unsigned)((g.nx + kXB - 1) / kXB) * (unsigned)((((nl + 7) >> 3) + 255) >> 8);
-  if (V == 4)
-    hipLaunchKernelGGL(esdf_y_kernel<4>, dim3(yblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2,
-                       (const int *)cols, (const int *)rank, (const int *)cnt);
-  else
-    hipLaunchKernelGGL(esdf_y_kernel<1>, dim3(yblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2,
-                       (const int *)cols, (const int *)rank, (const int *)cnt);
+  auto x_blocks = [&](int lanes, int block) {   // esdf_x_lane's grid: 8 XCDs x slab blocks x workgroups per XCD
+#ifdef GTOP_ESDF_X_PARTS
+    const int per_xcd = (lanes + 7) >> 3;
+#else
+    const int per_xcd = ((((lanes + 63) >> 6) + 7) >> 3) * 64;
+#endif
+    return 8u * (unsigned)((g.nx + kXB - 1) / kXB) * (unsigned)((per_xcd + block - 1) / block);
+  };
+  const unsigned xblocks = x_blocks(nl, 256);
+#ifndef GTOP_ESDF_X16
+#define GTOP_ESDF_X16 1
+#endif
+  const bool x16 = GTOP_ESDF_X16 && V == 4 && nyz % 8 == 0;   // the packed 16-bit x sweep (8 voxels per lane)
+  uint16_t *y16 = x16 ? f16 : (uint16_t *)nullptr;
+#define GTOP_Y_LAUNCH(VV, LL)                                                                                       \
+  hipLaunchKernelGGL((esdf_y_kernel<VV, LL>), dim3(yblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2, y16, \
+                     (const int *)cols, (const int *)rank, (const int *)cnt, (const uint8_t *)colany)
+  if (V == 4) {
+    if (ylocal) GTOP_Y_LAUNCH(4, true);
+    else GTOP_Y_LAUNCH(4, false);
+  } else {
+    if (ylocal) GTOP_Y_LAUNCH(1, true);
+    else GTOP_Y_LAUNCH(1, false);
+  }
+#undef GTOP_Y_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (V == 4)
+  if (x16) {
+    hipLaunchKernelGGL(esdf_x16_kernel, dim3(x_blocks(nyz >> 3, kX16Block)), dim3(kX16Block), 0, stream, g, (const uint16_t *)f16,
+                       (const int *)tmp2, dist, dist32);
+  } else if (V == 4)
     hipLaunchKernelGGL(esdf_x_kernel<4>, dim3(xblocks), dim3(256), 0, stream, g, (const int *)tmp2, dist, dist32);
   else
     hipLaunchKernelGGL(esdf_x_kernel<1>, dim3(xblocks), dim3(256), 0, stream, g, (const int *)tmp2, dist, dist32);

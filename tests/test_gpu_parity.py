@@ -35,6 +35,49 @@ def test_esdf_bit_exact(scene):
     assert np.array_equal(d, sdf.dist)
 
 
+@pytest.mark.parametrize("grid,kind", [
+    ((40, 24, 16), "random"),        # packed 16-bit x sweep (nz % 4 == 0, ny*nz % 8 == 0)
+    ((300, 8, 8), "one_end"),        # free space wider than 255 voxels: saturated values -> the 32-bit scan
+    ((100, 16, 16), "low_x"),        # slabs without any obstacle (no finite value after the y sweep)
+    ((64, 64, 12), "single"),        # one obstacle voxel
+    ((17, 10, 6), "random"),         # nz % 4 != 0: one voxel per lane
+    ((20, 5, 4), "random"),          # ny*nz % 8 != 0: 32-bit x sweep with four voxels per lane
+    ((3, 2, 8), "single"),           # lines shorter than a slab block
+    ((260, 260, 8), "corner"),       # in-plane distances past 255 voxels next to small ones
+    ((4, 2056, 8), "random"),        # ny past the y sweep's in-LDS candidate list: esdf_rows_kernel's lists
+    ((70, 130, 68), "random"),       # two 64-voxel chunks per column, several ballots per slab's column flags
+])
+def test_esdf_grid_shapes_bit_exact(gtop, grid, kind):
+    """The exact EDT on grid shapes that pick each sweep variant, against scipy's exact transform."""
+    from scipy import ndimage
+    nx, ny, nz = grid
+    rng = np.random.default_rng(nx * 1000 + ny * 10 + nz)
+    occ = np.zeros(grid, dtype=np.uint8)
+    if kind == "random":
+        occ[rng.random(grid) < 0.03] = 1
+        occ[0, 0, 0] = 1
+    elif kind == "one_end":
+        occ[0, 3, 4] = 1
+        occ[2, 0, 1] = 1
+    elif kind == "low_x":
+        occ[:5][rng.random((5, ny, nz)) < 0.1] = 1
+        occ[1, 2, 3] = 1
+    elif kind == "single":
+        occ[nx // 2, ny // 3, nz // 2] = 1
+    elif kind == "corner":
+        occ[:6, :6, :][rng.random((6, 6, nz)) < 0.3] = 1
+        occ[0, 0, 0] = 1
+    res = 0.2
+    mp = problem.MapSpec(grid, res, np.array([-nx * res / 2, -ny * res / 2, 0.0]), occ)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, res)
+    assert tuple(ctx.grid) == grid
+    ctx.update_sdf_map(mp.obstacle_points())
+    d = ctx.get_sdf()
+    ref = res * ndimage.distance_transform_edt(occ == 0)
+    assert np.array_equal(d, ref)
+
+
 @pytest.mark.parametrize("m", [2, 3, 6, 7, 10, 12, 17])
 @pytest.mark.parametrize("kw", [dict(), dict(step=1), dict(wc=0.0), dict(ws=0.0), dict(ws=20.0, wc=1.0)])
 def test_fp64_parity_host_api(scene, oracle_mod, m, kw):
