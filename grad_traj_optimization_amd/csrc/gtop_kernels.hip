@@ -112,6 +112,22 @@ __device__ unsigned long long g_gtop_stamps[4096][16];
 #define GTOP_STAMP_HWID()
 #endif
 
+// A phase boundary the compiler holds: the scheduling barrier alone only binds the machine scheduler, and by then
+// instruction selection has already placed the (side-effect-free) loads and arithmetic wherever it liked — in the
+// shipped build both barriers of the sample loop had ended up next to each other in front of the input wait and the
+// first sample's corner loads were waited for 20 instructions after their issue.  The empty asm with a memory
+// clobber orders the loads at the IR level; the barriers then keep the machine scheduler from undoing it.
+#ifndef GTOP_NO_PHASE_FENCE
+#define GTOP_PHASE_FENCE()                  \
+  do {                                      \
+    __builtin_amdgcn_sched_barrier(0);      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+#else
+#define GTOP_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // Diagnostic (-DGTOP_MARKS): comment markers in the ISA at region boundaries of gtop_eval_wave_kernel (pinned with
 // scheduling barriers) so that instructions can be counted per region with tools/isa_regions.py.
 #ifdef GTOP_MARKS
@@ -301,15 +317,15 @@ __device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, const
            (px > box.hi[0]) | (py > box.hi[1]) | (pz > box.hi[2]);
   const R rinv = box.rinv, half = box.half;
   // posToIndex(pos - 0.5 res)  (:201-204 -> :71-74)
-  const R ux = ((px - half) - box.org[0]) * rinv;
-  const R uy = ((py - half) - box.org[1]) * rinv;
-  const R uz = ((pz - half) - box.org[2]) * rinv;
+  const R tx = (px - half) - box.org[0], ty = (py - half) - box.org[1], tz = (pz - half) - box.org[2];
+  const R ux = tx * rinv, uy = ty * rinv, uz = tz * rinv;
   const R fx = gfloor(ux), fy = gfloor(uy);
   const int ix = (int)fx, iy = (int)fy, iz = (int)gfloor(uz);
   // indexToPos (:76-78) and diff (:209): (pos - centre(idx)) / res is the fractional
-  // part of u (equal up to a few ulp of u, ~1e-14 of a voxel)
-  tp.dx = ux - fx;
-  tp.dy = uy - fy;
+  // part of u (equal up to a few ulp of u, ~1e-14 of a voxel).  Written as the fused form the compiler
+  // contracts `u - floor(u)` to where it can: every body, however it is scheduled, takes the same bits.
+  tp.dx = gfma(tx, rinv, -fx);
+  tp.dy = gfma(ty, rinv, -fy);
 
   // z is the fastest axis, so the two z-corners of each (x,y) column are one
   // 2-element load; the clamp at the z borders becomes a clamp of the weight.
@@ -317,7 +333,62 @@ __device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, const
   // At a z border both z-corners clamp to the same voxel (:166-174); with the
   // pair (D[zb], D[zb+1]) in hand that is dz := 0 (iz < 0) or dz := 1
   // (iz > nz-2) — i.e. uz - zb clamped to [0,1] — and a zero z-gradient.
-  tp.dze = gmin(gmax(uz - (R)zb, (R)0), (R)1);
+  tp.dze = gmin(gmax(gfma(tz, rinv, -(R)zb), (R)0), (R)1);
+  tp.zflat = iz != zb;
+  return tp;
+}
+
+// The same with the four pair loads issued by hand (fp64, 32-bit offsets): the lone-wavefront body wants all of a
+// lane's corner loads in flight BEFORE the arithmetic that does not need them, and the compiler — free to sink
+// side-effect-free loads of a read-only noalias field, and keen to, at 232 VGPRs — put each sample's loads right in
+// front of their use (round 2: the first sample's loads were waited for 20 instructions after their issue, whatever
+// scheduling barriers said).  A volatile asm keeps its place among the phase fences; the compiler does not count
+// these loads, so the caller waits for them itself (gtop_wait_pairs) before it reads `raw`.
+typedef double gtop_d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ gtop_d2 asm_load_pair(const void *base, uint32_t byte_off) {
+  gtop_d2 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base));
+  return v;
+}
+
+// s_waitcnt vmcnt(LEFT) on the hand-issued loads (in issue order, LEFT of them may still be in flight); `raw` passes
+// through, so that nothing reads it before the wait, and `after0/1` are values that must be complete first.
+template <int LEFT>
+__device__ __forceinline__ void gtop_wait_pairs(gtop_d2 (&raw)[4], double after0, double after1) {
+  asm volatile("s_waitcnt vmcnt(%6)"
+               : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3])
+               : "v"(after0), "v"(after1), "n"(LEFT));
+}
+
+__device__ __forceinline__ SdfTap<double> sdf_issue_asm(const GtopKernelArgs<double> &a, const MapBox<double> &box,
+                                                        double px, double py, double pz, gtop_d2 (&raw)[4]) {
+  typedef double R;
+  SdfTap<R> tp;
+  tp.out = (px < box.lo[0]) | (py < box.lo[1]) | (pz < box.lo[2]) |
+           (px > box.hi[0]) | (py > box.hi[1]) | (pz > box.hi[2]);
+  const R rinv = box.rinv, half = box.half;
+  const R tx = (px - half) - box.org[0], ty = (py - half) - box.org[1], tz = (pz - half) - box.org[2];
+  const R ux = tx * rinv, uy = ty * rinv, uz = tz * rinv;
+  const R fx = gfloor(ux), fy = gfloor(uy);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)gfloor(uz);
+  tp.dx = gfma(tx, rinv, -fx);
+  tp.dy = gfma(ty, rinv, -fy);
+  // corner_loads<double, false>, loads by hand
+  const int nx = a.nx, ny = a.ny, nz = a.nz;
+  const int x0 = min(max(ix, 0), nx - 1);
+  const int y0 = min(max(iy, 0), ny - 1);
+  const int zb = min(max(iz, 0), nz - 2);
+  const bool cx = (unsigned)ix < (unsigned)(nx - 1), cy = (unsigned)iy < (unsigned)(ny - 1);
+  const uint32_t o00 = (__umul24(__umul24((uint32_t)x0, (uint32_t)ny) + (uint32_t)y0, (uint32_t)nz) + (uint32_t)zb) * 8u;
+  const uint32_t sy = cy ? (uint32_t)nz * 8u : 0u;
+  const uint32_t sx = cx ? (uint32_t)ny * (uint32_t)nz * 8u : 0u;
+  const uint32_t o10 = o00 + sx;
+  raw[0] = asm_load_pair(a.sdf, o00);
+  raw[1] = asm_load_pair(a.sdf, o00 + sy);
+  raw[2] = asm_load_pair(a.sdf, o10);
+  raw[3] = asm_load_pair(a.sdf, o10 + sy);
+  tp.dze = gmin(gmax(gfma(tz, rinv, -(R)zb), (R)0), (R)1);
   tp.zflat = iz != zb;
   return tp;
 }
@@ -1283,6 +1354,11 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // and only one sample's corners are live (the 168-VGPR budget of a third wavefront).
     constexpr int CH = (MINW <= 2) ? SPL : 1;
     constexpr int kUnrollJ = SPL <= 3 ? SPL : 1;   // six samples per lane stay a loop (code size)
+#ifndef GTOP_ASM_LOADS
+#define GTOP_ASM_LOADS 1
+#endif
+    // hand-issued corner loads (sdf_issue_asm): the lone-wavefront fp64 body with 32-bit field offsets
+    constexpr bool ASMLD = GTOP_ASM_LOADS && !kIsF32<R> && !WIDE && MINW <= 2 && SPL == 3 && !MMA;   // (MMA: no registers left)
     if constexpr (kIsF32<R> && SPL % 2 == 0) {
       // packed fp32 (see sample_pair_f32): samples jj and jj+1 of this lane together in float2 registers
       jerk_init();
@@ -1311,6 +1387,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       // stage A: positions, index arithmetic, corner loads
       R vels[CH][3];
       SdfTap<R> taps[CH];
+      gtop_d2 raw[ASMLD ? CH : 1][4];
       if constexpr (MINW > 2) sample_time(j0, ts[0], aw[0]);
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
@@ -1324,10 +1401,11 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
           pos[k] = round_through_float(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
           vels[c][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
         }
-        taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
+        if constexpr (ASMLD) taps[c] = sdf_issue_asm(a, mapbox, pos[0], pos[1], pos[2], raw[c]);
+        else taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
       }
       if (j0 == 0) GTOP_STAMP(4);   // corner loads issued
-      if constexpr (CH == SPL) __builtin_amdgcn_sched_barrier(0);   // every corner load is issued above this line ...
+      if constexpr (CH == SPL) GTOP_PHASE_FENCE();   // every corner load is issued above this line ...
       // ... and what does not need them runs while they are in flight: the jerk term and the speeds
       if constexpr (MINW <= 2) jerk_init();
       R vns[CH], ivns[CH];
@@ -1345,10 +1423,24 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         GTOP_STAMP(6);   // corner loads landed
       }
 #endif
-      if constexpr (CH == SPL) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (CH == SPL) GTOP_PHASE_FENCE();
       // stage B: trilinear blend, penalty, accumulation
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
+        if constexpr (ASMLD) {
+          // sample c's four loads have landed once at most 4*(CH-1-c) of the later ones are in flight; the jerk
+          // term, the speeds and the previous sample's accumulation come first
+          // (acc[3], acc[17]: operands of explicit fmas — an extra use of a bare product such as acc[18] = wj*jc would
+          // change whether the compiler contracts it with the next addition, and with it the last bit against the
+          // variants of this kernel that load the ordinary way)
+          if (CH - 1 - c == 2) gtop_wait_pairs<8>(raw[c], acc[3], acc[17]);
+          else if (CH - 1 - c == 1) gtop_wait_pairs<4>(raw[c], acc[3], acc[17]);
+          else gtop_wait_pairs<0>(raw[c], acc[3], acc[17]);
+          taps[c].p00.x = raw[c][0].x; taps[c].p00.y = raw[c][0].y;
+          taps[c].p01.x = raw[c][1].x; taps[c].p01.y = raw[c][1].y;
+          taps[c].p10.x = raw[c][2].x; taps[c].p10.y = raw[c][2].y;
+          taps[c].p11.x = raw[c][3].x; taps[c].p11.y = raw[c][3].y;
+        }
         const R t = ts[MINW <= 2 ? j0 + c : 0];
         const R *vel = vels[c];
         const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
