@@ -1267,8 +1267,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
                       {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
   if constexpr (COLLI && !kIsF32<R> && MINW <= 2 && !MMA) {   // (the optimizer loop has no registers to spare)
+    // the exp constants only: with the map box pinned as well (12 more VGPRs) the body spills two registers since
+    // the hand-issued loads hold all 12 corner pairs at once — 4.45 against 4.23 us
     expk.pin();
-    mapbox.pin();
   }
 #ifdef GTOP_STAMPS
   GTOP_STAMP(2);   // inputs requested
@@ -1451,7 +1452,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         const R e = penalty_exp((pen_d0 - dist) * pen_inv_r, expk);   // exp(-(d - d0)/r)
         const R cdw = aw[MINW <= 2 ? j0 + c : 0] * e;   // wc*dt * cd, cd of :509 (idle lanes: shadow data, never read)
         const R cv = cdw * vn;
-        acc[18] += cv;                // :373, weighted as in :417-418
+        acc[18] = gfma(cdw, vn, acc[18]);   // += cv: :373, weighted as in :417-418 (fusions are spelled out: -ffp-contract=on)
         // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381); gd of :514
         const R f1 = is_out ? (R)0 : ((pen_gd * a.res_inv) * e) * cv, f2 = cdw * ivn;
         const R d2 = (R)2 * t, d3 = K.k3 * t2, d4 = (R)4 * t3, d5 = K.k5 * t4;
@@ -1459,8 +1460,8 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         for (int k = 0; k < 3; ++k) {
           const R w1k = f1 * g3[k], w2k = f2 * vel[k];
           R *ak = acc + 6 * k;
-          ak[0] += w1k;
-          ak[1] = gfma(w1k, t, ak[1] + w2k);
+          ak[0] = gfma(f1, g3[k], ak[0]);
+          ak[1] = gfma(w1k, t, gfma(f2, vel[k], ak[1]));
           ak[2] = gfma(w1k, t2, gfma(w2k, d2, ak[2]));
           ak[3] = gfma(w1k, t3, gfma(w2k, d3, ak[3]));
           ak[4] = gfma(w1k, t4, gfma(w2k, d4, ak[4]));
