@@ -1606,7 +1606,9 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
     GtopKernelArgs<R> wa = args;
     if (wa.step == 1) wa.ws = (R)0;   // :412-415, applied here so that the kernel need not fetch `step`
     const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
-    const bool three = args.B >= GTOP_WAVE_MINW3_FROM;
+    // (64-bit field indices — fields past 4 GiB — cost the 168-VGPR fp64 body 14 spilled registers: those stay on
+    // the two-wavefront budget)
+    const bool three = args.B >= GTOP_WAVE_MINW3_FROM && !(WIDE && sizeof(R) == 8);
     const size_t wsmem = (kRedVals * red_stride(spl) + 128) * sizeof(R);   // tile + the optimizer's gradient rows
     if constexpr (MMA) {
       if constexpr (sizeof(R) == 8) {
