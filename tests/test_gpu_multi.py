@@ -91,3 +91,34 @@ def test_two_contexts_on_one_device_equal_the_unsharded_batch(gtop):
         torch.cuda.synchronize()
         assert torch.equal(torch.cat([p[0] for p in parts]), c_all)
         assert torch.equal(torch.cat([p[1] for p in parts]), g_all)
+
+
+@pytest.mark.timeout(900)
+def test_configs3_batch_in_eight_shards_equals_the_whole(gtop):
+    """BASELINE.json configs[3] at full size on one card: 131 072 trajectories over the 200^3 field, evaluated whole
+    and as the eight contiguous 16 384-row shards the eight ranks of `bench.py --gpus 8 --batch 16384` would own.
+    Rows are independent and the auto rule picks the same body for a shard as for the whole batch (both past the
+    3 072-row switch), so the concatenation is bit-identical; plus cost >= 1e-3 (:417-418) and finite gradients."""
+    import torch
+    mp = problem.make_map(200, density=0.02, seed=0)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    B, W = 131072, 8
+    b = problem.make_trajectories(B, 6, mp, seed=4)
+    dev = torch.device("cuda:0")
+    x = torch.tensor(b.x, device=dev)
+    Df = torch.tensor(b.Df.reshape(-1, 18), device=dev)
+    T = torch.tensor(b.T, device=dev)
+    c_all, g_all = ctx.eval_device(x, Df, T)
+    torch.cuda.synchronize()
+    assert torch.isfinite(c_all).all() and torch.isfinite(g_all).all() and (c_all >= 1e-3).all()
+    covered = 0
+    for r in range(W):
+        lo, hi = problem.shard_range(B, r, W)
+        assert lo == covered and hi - lo == B // W
+        covered = hi
+        c, g = ctx.eval_device(x[lo:hi].contiguous(), Df[lo:hi].contiguous(), T[lo:hi].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(c, c_all[lo:hi]) and torch.equal(g, g_all[lo:hi])
+    assert covered == B
