@@ -56,6 +56,39 @@ def test_nlopt_entry_point_and_bookkeeping(scene, oracle_mod):
         ctx.cost_nlopt(b.x[0][:-1])                                   # n != 9(m-1)
 
 
+def test_small_host_batches_complete_by_polling_or_by_stream_wait(scene, gtop, monkeypatch):
+    """gtop_eval_batch on small batches returns when the last output has landed in coherent host memory (no end-of-kernel
+    protocol); GTOP_POLL_COMPLETION=0 waits through the stream instead.  Same bits either way, for batches inside the
+    polled size, past it, and past the zero-copy size; a NaN input comes back as NaN, promptly."""
+    import time
+    mp, ctx0, sdf = scene
+    ctxs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GTOP_POLL_COMPLETION", mode)       # read at gtop_create
+        c = gtop.GtopContext(device=0)
+        c.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+        c.update_sdf_map(mp.obstacle_points())
+        c.set_params()
+        ctxs[mode] = c
+    for B in (1, 7, 22, 23, 300, 4000):                         # 22 x 46 outputs = the last polled size at m = 6
+        b = problem.make_trajectories(B, 6, mp, seed=70 + B)
+        res = []
+        for mode in ("1", "0"):
+            ctxs[mode].set_problem(b.T, b.Df)
+            for _ in range(3):                                   # the staging buffer is reused call after call
+                c, g = ctxs[mode].eval_batch(b.x)
+            res.append((c, g))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    b = problem.make_trajectories(1, 6, mp, seed=9)
+    ctxs["1"].set_problem(b.T, b.Df)
+    x = b.x.copy()
+    x[0, 3] = np.nan
+    ctxs["1"].eval_batch(x)
+    t0 = time.perf_counter()
+    c, g = ctxs["1"].eval_batch(x)
+    assert np.isnan(c[0]) and (time.perf_counter() - t0) < 1e-3   # not the poll's 2 ms timeout
+
+
 def test_error_codes(gtop):
     ctx = gtop.GtopContext(device=0)
     with pytest.raises(gtop.GtopError) as e:
