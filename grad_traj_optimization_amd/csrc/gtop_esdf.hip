@@ -53,14 +53,18 @@ namespace {
 
 constexpr int kInf = 0x3fffffff;   // "no obstacle on this line so far"; d^2 + kInf stays below 2^31 for lines <= 2^15
 
+// resetBuffer (sdf_map.cpp:26-53).  16 occupancy bytes per lane and store (hipMalloc'd: 256-byte aligned); the
+// last nvox % 16 bytes one at a time.
 __global__ void __launch_bounds__(256)
 esdf_reset_kernel(uint8_t *__restrict__ occ, double *__restrict__ dist, size_t nvox) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < nvox; i += stride) {
-    occ[i] = 0;
-    if (dist) dist[i] = 10000.0;   // sdf_map.cpp:22, :51
-  }
+  const size_t nq = nvox >> 4;
+  uint4 *occ16 = reinterpret_cast<uint4 *>(occ);
+  for (size_t i = tid; i < nq; i += stride) occ16[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = (nq << 4) + tid; i < nvox; i += stride) occ[i] = 0;
+  if (dist)
+    for (size_t i = tid; i < nvox; i += stride) dist[i] = 10000.0;   // sdf_map.cpp:22, :51
 }
 
 __global__ void __launch_bounds__(256)
@@ -131,9 +135,10 @@ esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict
 
 // The same for columns of up to 256 voxels (NCH <= 4 chunks of 64): the ballots stay in scalar registers, what the
 // other chunks contribute to a chunk (their highest occupied voxel below it, their lowest above it) is scalar
-// arithmetic done once per column, and a lane only searches its own chunk's mask (21 -> 18 us at 200^3; what is
-// left is one dependent round trip per wavefront generation — storing the distance as a byte instead of its square
-// as an int made this sweep 2 us faster and the y sweep 2.4 us slower).
+// arithmetic done once per column, and a lane only searches its own chunk's mask (21 -> 18 us at 200^3).  What is
+// left is instruction issue — 160 VALU + 81 SALU per column, 39 columns per SIMD — not latency: four columns per
+// trip with all their loads issued first made it slower (20.6 us); storing the distance as a byte instead of its
+// square as an int made this sweep 2 us faster and the y sweep 2.4 us slower.
 template <int NCH>
 __global__ void __launch_bounds__(256)
 esdf_z_small_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out,
