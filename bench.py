@@ -453,14 +453,35 @@ def main():
         dist.destroy_process_group()
 
 
-def _time_evals(ctx, x, Df, T, reps):
-    """us per launch of gtop_eval_device on torch's current stream (HIP events)."""
+def _time_evals(ctx, x, Df, T, reps, per_graph=20):
+    """us per launch of gtop_eval_device (HIP events on torch's current stream), measured the way the timed region
+    is: replays of a hipGraph of `per_graph` launches after a warm-up of the same graph (eager launches put the
+    inter-launch gap of the host's queue into every sample, and five warm-up launches left the clocks low: the
+    same kernel read 41 us here and 36 us in its own bench run).  Eager launches if the capture fails."""
     import torch
     cost, grad = ctx.eval_device(x, Df, T)
     for _ in range(5):
         ctx.eval_device(x, Df, T, cost, grad)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph, capture_error_mode="thread_local"):
+            for _ in range(per_graph):
+                ctx.eval_device(x, Df, T, cost, grad)
+        nrep = max(2, reps // per_graph)
+        for _ in range(nrep):          # warm-up: as much work as the timed part
+            gph.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(nrep):
+            gph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (nrep * per_graph) * 1e3
+    except Exception as e:
+        print(f"bench.py: extras: graph capture failed ({e}); eager launches", file=sys.stderr)
+        torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
         ctx.eval_device(x, Df, T, cost, grad)
@@ -470,7 +491,7 @@ def _time_evals(ctx, x, Df, T, reps):
 
 
 def _extra_workload(ctx, oracle, osdf, b, m, grid, name, dev, label, reps=200):
-    """One more BASELINE.json workload: parity gate on 256 rows, then timed eager launches."""
+    """One more BASELINE.json workload: parity gate on 256 rows, then timed graph replays (_time_evals)."""
     import torch
     dt = torch.float64 if name == "f64" else torch.float32
     xb = torch.tensor(b.x, dtype=dt, device=dev)
@@ -495,7 +516,7 @@ def _extra_workload(ctx, oracle, osdf, b, m, grid, name, dev, label, reps=200):
 
 def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
     """Not part of `value`: (1) the other single-GPU BASELINE.json workloads
-    (each behind its own 256-row parity gate; eager launches, HIP-event time
+    (each behind its own 256-row parity gate; hipGraph replays, HIP-event time
     per launch), (2) the batched optimizer driver on the bench
     batch."""
     import torch
