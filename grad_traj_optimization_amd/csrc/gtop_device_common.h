@@ -48,15 +48,32 @@ __device__ __forceinline__ R gtop_wave_sum(R v) {
 // zero nonlinear constraints: the separable minimiser is closed form).
 // state[b]: 0 = first evaluation pending, 1 = inside an inner loop.
 // ---------------------------------------------------------------------------
+// The update's view of ONE trajectory's state: its n-vectors (base pointers of this trajectory's rows — in global
+// memory for the launch forms that keep the state there between launches, in LDS for the one-launch loop, which then
+// pays no global round trip for them between its passes) and its scalars.  `xcur` is what the update reads;
+// `xcur_out` is where the next trial point is ALSO written when the evaluation reads it from elsewhere (the global
+// row, for the loop) — the same pointer otherwise.
+struct GtopMmaVecs {
+  double *x, *xcur, *xprev, *xprevprev, *dfdx, *sigma;
+  const double *lb, *ub;
+  double *xcur_out;
+};
+struct GtopMmaScalars {
+  double rho, minf, gval, wval, fprev;
+  int k, state, nevals;
+};
+
 __device__ __forceinline__ void gtop_mma_separable_step(int n, int lane, const double *x, const double *dfdx,
                                                         const double *sigma, double rho, const double *lb,
-                                                        const double *ub, double *xcur, double &g, double &w) {
+                                                        const double *ub, double *xcur, double *xcur_out, double &g,
+                                                        double &w) {
   g = 0.0;
   w = 0.0;
   for (int j = lane; j < n; j += 64) {
     const double sg = sigma[j], xj = x[j];
     if (sg == 0.0) {
       xcur[j] = xj;
+      if (xcur_out != xcur) xcur_out[j] = xj;
       continue;
     }
     const double df = dfdx[j];
@@ -70,6 +87,7 @@ __device__ __forceinline__ void gtop_mma_separable_step(int n, int lane, const d
     const double hi = xj + 0.9 * sg, lo = xj - 0.9 * sg;
     xc = xc > hi ? hi : (xc < lo ? lo : xc);
     xcur[j] = xc;
+    if (xcur_out != xcur) xcur_out[j] = xc;
     dx = xc - xj;
     const double dx2 = dx * dx;
     const double denominv = 1.0 / (sigma2 - dx2);
@@ -78,71 +96,65 @@ __device__ __forceinline__ void gtop_mma_separable_step(int n, int lane, const d
   }
 }
 
-// gcur: this trajectory's gradient at xcur (n values; global or LDS)
-__device__ __forceinline__ void gtop_mma_update_trajectory(const GtopMmaState &st, int b, int n, int lane,
-                                                           double fcur, const double *gcur) {
-  const size_t o = (size_t)b * n;
-  double *x = st.x + o, *xcur = st.xcur + o, *xprev = st.xprev + o, *xprevprev = st.xprevprev + o;
-  double *dfdx = st.dfdx + o, *sigma = st.sigma + o;
-  const double *lb = st.lb + o, *ub = st.ub + o;
-  const int state = st.state[b];
-  if (state >= 3) return;   // stopped (wavefront-uniform): the trajectory stays as it was left
-  double rho = st.rho[b], minf = st.minf[b];
-  int k = st.k[b];
-  const int nevals = st.nevals[b] + 1;   // this evaluation
+// One update on the state `v` / `sc` (see gtop_mma_update_trajectory).  st: the stop tolerances only.
+// gcur: this trajectory's gradient at xcur (n values; global or LDS).
+__device__ __forceinline__ void gtop_mma_update_core(const GtopMmaState &st, const GtopMmaVecs &v, GtopMmaScalars &sc,
+                                                     int n, int lane, double fcur, const double *gcur) {
+  if (sc.state >= 3) return;   // stopped (wavefront-uniform): the trajectory stays as it was left
+  double rho = sc.rho, minf = sc.minf;
+  int k = sc.k;
+  const int nevals = sc.nevals + 1;   // this evaluation
   bool new_outer;
 
-  if (state == 0) {
+  if (sc.state == 0) {
     // f(x0): base point = start (mma.hpp: first evaluation)
     minf = fcur;
     for (int j = lane; j < n; j += 64) {
-      x[j] = xcur[j];
-      dfdx[j] = gcur[j];
+      v.x[j] = v.xcur[j];
+      v.dfdx[j] = gcur[j];
     }
     new_outer = true;
   } else {
-    const double gval = st.gval[b], wval = st.wval[b];
+    const double gval = sc.gval, wval = sc.wval;
     const bool inner_done = gval >= fcur;
     if (fcur < minf) {   // accept: new base point
       minf = fcur;
       for (int j = lane; j < n; j += 64) {
-        x[j] = xcur[j];
-        dfdx[j] = gcur[j];
+        v.x[j] = v.xcur[j];
+        v.dfdx[j] = gcur[j];
       }
     }
     if (inner_done) {
       // stop rules, where the host twin has them (mma.hpp:127-137): after the inner loop, on the last
       // evaluated f against the f the outer iteration started from, and on xcur against xprev
       int stop = 0;
-      const double fprev = st.fprev[b];
+      const double fprev = sc.fprev;
       if (st.ftol_rel > 0 && fabs(fcur - fprev) < st.ftol_rel * (fabs(fcur) + fabs(fprev)) * 0.5) stop = GTOP_MMA_FTOL_REACHED;
       if (!stop && st.xtol_rel > 0) {
         bool all = true;
         for (int j = lane; j < n; j += 64)
-          all = all && fabs(xcur[j] - xprev[j]) < st.xtol_rel * (fabs(xcur[j]) + fabs(xprev[j])) * 0.5;
+          all = all && fabs(v.xcur[j] - v.xprev[j]) < st.xtol_rel * (fabs(v.xcur[j]) + fabs(v.xprev[j])) * 0.5;
         if (__all(all)) stop = GTOP_MMA_XTOL_REACHED;
       }
       if (stop) {
-        if (lane == 0) {
-          st.minf[b] = minf;
-          st.nevals[b] = nevals;
-          st.state[b] = stop;
-        }
+        sc.minf = minf;
+        sc.nevals = nevals;
+        sc.state = stop;
         return;
       }
       // end of the outer iteration: relax rho, adapt the asymptotes
       rho = fmax(0.1 * rho, 1e-5);
       if (k > 1) {
         for (int j = lane; j < n; j += 64) {
-          const double dx2 = (xcur[j] - xprev[j]) * (xprev[j] - xprevprev[j]);
+          const double dx2 = (v.xcur[j] - v.xprev[j]) * (v.xprev[j] - v.xprevprev[j]);
           const double gam = dx2 < 0 ? 0.7 : (dx2 > 0 ? 1.2 : 1.0);
-          double s = sigma[j] * gam;
-          const double range = ub[j] - lb[j];
-          if (!isinf(ub[j]) && !isinf(lb[j])) {
+          double s = v.sigma[j] * gam;
+          const double range = v.ub[j] - v.lb[j];
+          if (!isinf(v.ub[j]) && !isinf(v.lb[j])) {
             s = fmin(s, 10 * range);
             s = fmax(s, 0.01 * range);
           }
-          sigma[j] = s;
+          v.sigma[j] = s;
         }
       }
       new_outer = true;
@@ -154,26 +166,47 @@ __device__ __forceinline__ void gtop_mma_update_trajectory(const GtopMmaState &s
   if (new_outer) {
     ++k;
     for (int j = lane; j < n; j += 64) {
-      if (k > 1) xprevprev[j] = xprev[j];
-      xprev[j] = xcur[j];
+      if (k > 1) v.xprevprev[j] = v.xprev[j];
+      v.xprev[j] = v.xcur[j];
     }
   }
   // every lane's writes above are to its own j; the step below reads x/dfdx/sigma
   // at the same j only, so no cross-lane hazard
   double g, w;
-  gtop_mma_separable_step(n, lane, x, dfdx, sigma, rho, lb, ub, xcur, g, w);
+  gtop_mma_separable_step(n, lane, v.x, v.dfdx, v.sigma, rho, v.lb, v.ub, v.xcur, v.xcur_out, g, w);
   g = gtop_wave_sum(g);
   w = gtop_wave_sum(w);
-  if (lane == 0) {
-    st.gval[b] = minf + g;
-    st.wval[b] = w;
-    st.rho[b] = rho;
-    st.minf[b] = minf;
-    st.k[b] = k;
-    st.state[b] = 1;
-    st.nevals[b] = nevals;
-    if (new_outer) st.fprev[b] = fcur;
-  }
+  sc.gval = minf + g;
+  sc.wval = w;
+  sc.rho = rho;
+  sc.minf = minf;
+  sc.k = k;
+  sc.state = 1;
+  sc.nevals = nevals;
+  if (new_outer) sc.fprev = fcur;
+}
+
+__device__ __forceinline__ GtopMmaScalars gtop_mma_load_scalars(const GtopMmaState &st, int b) {
+  GtopMmaScalars sc;
+  sc.rho = st.rho[b]; sc.minf = st.minf[b]; sc.gval = st.gval[b]; sc.wval = st.wval[b]; sc.fprev = st.fprev[b];
+  sc.k = st.k[b]; sc.state = st.state[b]; sc.nevals = st.nevals[b];
+  return sc;
+}
+__device__ __forceinline__ void gtop_mma_store_scalars(const GtopMmaState &st, int b, const GtopMmaScalars &sc) {
+  st.rho[b] = sc.rho; st.minf[b] = sc.minf; st.gval[b] = sc.gval; st.wval[b] = sc.wval; st.fprev[b] = sc.fprev;
+  st.k[b] = sc.k; st.state[b] = sc.state; st.nevals[b] = sc.nevals;
+}
+
+// The update with the state where the multi-launch forms keep it: global memory, read and written in place.
+__device__ __forceinline__ void gtop_mma_update_trajectory(const GtopMmaState &st, int b, int n, int lane,
+                                                           double fcur, const double *gcur) {
+  const size_t o = (size_t)b * n;
+  const GtopMmaVecs v = {st.x + o, st.xcur + o, st.xprev + o, st.xprevprev + o, st.dfdx + o, st.sigma + o,
+                         st.lb + o, st.ub + o, st.xcur + o};
+  GtopMmaScalars sc = gtop_mma_load_scalars(st, b);
+  if (sc.state >= 3) return;
+  gtop_mma_update_core(st, v, sc, n, lane, fcur, gcur);
+  if (lane == 0) gtop_mma_store_scalars(st, b, sc);
 }
 
 #endif  // GTOP_DEVICE_COMMON_H_

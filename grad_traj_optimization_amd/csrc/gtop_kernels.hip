@@ -1193,15 +1193,43 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     t_launch = wall_clock64();
     npass = st.iters;
   }
+  // The optimizer loop keeps its trajectory's state on the chip between passes: the eight n-vectors in LDS (behind
+  // the tile and the gradient rows; n <= 45 < 64, lane j owns entry j) and the scalars in registers; global memory
+  // sees the trial point of every pass (the evaluation reads its inputs from there) and everything else once, at
+  // the end.  With the state in global memory every pass paid five dependent round trips for it — 7 us per pass,
+  // of which the evaluation is 2.5.
+  [[maybe_unused]] double *mv = nullptr;   // [8][64]: x, xcur, xprev, xprevprev, dfdx, sigma, lb, ub
+  [[maybe_unused]] GtopMmaVecs mvecs = {};
+  [[maybe_unused]] GtopMmaScalars msc = {};
+  [[maybe_unused]] bool mma_live = false;
+  if constexpr (MMA) {
+    mv = reinterpret_cast<double *>(tile) + kRedVals * kStride + 128;
+    mvecs = GtopMmaVecs{mv, mv + 64, mv + 128, mv + 192, mv + 256, mv + 320, mv + 384, mv + 448,
+                        st.xcur + (size_t)b0 * n};
+    mma_live = grp_ok;
+    if (mma_live) {
+      msc = gtop_mma_load_scalars(st, b0);
+      const size_t o = (size_t)b0 * n;
+      if (lane < n) {
+        mv[lane] = st.x[o + lane];
+        mv[64 + lane] = st.xcur[o + lane];
+        mv[128 + lane] = st.xprev[o + lane];
+        mv[192 + lane] = st.xprevprev[o + lane];
+        mv[256 + lane] = st.dfdx[o + lane];
+        mv[320 + lane] = st.sigma[o + lane];
+        mv[384 + lane] = st.lb[o + lane];
+        mv[448 + lane] = st.ub[o + lane];
+      }
+    }
+  }
   for (int pass = 0; pass < npass; ++pass) {
   const R *xsrc = a.x;
   if constexpr (MMA) {
     // stop rules (mma.hpp:35-39; set_maxtime, :144-148), wave-uniform: a trajectory that has stopped (ftol / xtol in the
     // update) leaves the loop; past the wall-clock limit a running one stops where it is, after at least one evaluation
-    const int stt = __hip_atomic_load(&st.state[b0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!grp_ok || stt >= 3) break;
+    if (!mma_live || msc.state >= 3) break;
     if (st.max_ticks > 0 && pass > 0 && (long long)(wall_clock64() - t_launch) > st.max_ticks) {
-      if (lane == 0) st.state[b0] = GTOP_MMA_MAXTIME_REACHED;
+      msc.state = GTOP_MMA_MAXTIME_REACHED;
       break;
     }
     xsrc = reinterpret_cast<const R *>(st.xcur);   // (not the __restrict__ argument: the update below rewrites it)
@@ -1539,7 +1567,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       const double fcur = __builtin_bit_cast(double, ((unsigned long long)hi32 << 32) | lo32);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
       __builtin_amdgcn_wave_barrier();
-      gtop_mma_update_trajectory(st, b0, n, lane, fcur, reinterpret_cast<const double *>(gl));
+      gtop_mma_update_core(st, mvecs, msc, n, lane, fcur, reinterpret_cast<const double *>(gl));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is rewritten by the next evaluation
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -1552,6 +1580,21 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   GTOP_STAMP(11);   // stores acknowledged
 #endif
   }   // pass
+  if constexpr (MMA) {
+    if (mma_live) {   // the state goes home (xcur is there already)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const size_t o = (size_t)b0 * n;
+      if (lane < n) {
+        st.x[o + lane] = mv[lane];
+        st.xprev[o + lane] = mv[128 + lane];
+        st.xprevprev[o + lane] = mv[192 + lane];
+        st.dfdx[o + lane] = mv[256 + lane];
+        st.sigma[o + lane] = mv[320 + lane];
+      }
+      if (lane == 0) gtop_mma_store_scalars(st, b0, msc);
+    }
+  }
 }
 
 }  // namespace
@@ -1609,7 +1652,8 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
     // (64-bit field indices — fields past 4 GiB — cost the 168-VGPR fp64 body 14 spilled registers: those stay on
     // the two-wavefront budget)
     const bool three = args.B >= GTOP_WAVE_MINW3_FROM && !(WIDE && sizeof(R) == 8);
-    const size_t wsmem = (kRedVals * red_stride(spl) + 128) * sizeof(R);   // tile + the optimizer's gradient rows
+    // tile + the optimizer's gradient rows (+ its state: 8 vectors of 64, gtop_eval_wave_kernel)
+    const size_t wsmem = (kRedVals * red_stride(spl) + 128 + (MMA ? 512 : 0)) * sizeof(R);
     if constexpr (MMA) {
       if constexpr (sizeof(R) == 8) {
         if (one && spl == 3) {
