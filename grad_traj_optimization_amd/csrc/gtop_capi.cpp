@@ -796,7 +796,9 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   st.ftol_rel = stop->ftol_rel;
   st.xtol_rel = stop->xtol_rel;
   st.max_ticks = (long long)(stop->maxtime * 1e8);   // wall_clock64(): 100 MHz
-  HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
+  st.x0_init = nullptr;
+  st.out_x = st.out_minf = nullptr;
+  st.out_code = st.out_nevals = nullptr;
   int waves, spl, tpb;
   // whole loop in one launch: the unrolled one-trajectory-per-wavefront body wins at every batch
   // size (measured 1024 ... 16384, tools/opt_time.py); otherwise the evaluation kernel's own rule
@@ -804,20 +806,37 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   const bool fused = c->fuse_mma != 0 && (spl == 1 || spl == 3 || spl == 6);
   const bool resident = fused && c->fuse_mma == 2;   // one launch runs all max_evals evaluations of every trajectory
   st.iters = resident ? max_evals : 1;
+  GtopKernelArgs<double> a;
+  fill_args(c, a);
+  a.sdf = c->sdf64;
+  a.x = st.xcur;
+  a.Df = static_cast<const double *>(d_Df);
+  a.T = static_cast<const double *>(d_T);
+  a.cost = c->mma_f;
+  a.grad = c->mma_g;
+  a.B = B; a.m = m; a.t_stride = time_stride;
+  if (fused)
+    while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(double)) > 64 * 1024) --tpb;
+  a.tpb = tpb;
+  // The whole optimisation as ONE launch where the loop runs in gtop_eval_wave_kernel (m <= 6): it initialises
+  // the state from d_x itself and writes the results where they are wanted — no init kernel in front, no copies
+  // and no finish kernel behind (each a stream operation of its own: 75 -> ~25 us of fixed cost per call).
+  const bool single = resident && gtop_eval_mma_is_wave_loop(a, waves, spl, c->prm.enable_dyn != 0, 1 << 20);
+  if (single) {
+    st.x0_init = static_cast<const double *>(d_x);
+    // the kernel reads the start points row by row before it writes anything there, and a row is read and written
+    // by the same wavefront: d_x can be the output as well
+    st.out_x = static_cast<double *>(d_x);
+    st.out_minf = static_cast<double *>(d_minf);
+    st.out_code = d_code;
+    st.out_nevals = d_nevals;
+    HIPCHK(c, gtop_launch_eval_mma(a, st, waves, spl, false, 1 << 20, s));
+    return GTOP_OK;
+  }
+  HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
   for (int it = 0; it < (resident ? 1 : max_evals); ++it) {
     if (fused) {
       // one launch per iteration: the evaluation kernel runs the MMA update as its epilogue
-      GtopKernelArgs<double> a;
-      fill_args(c, a);
-      a.sdf = c->sdf64;
-      a.x = st.xcur;
-      a.Df = static_cast<const double *>(d_Df);
-      a.T = static_cast<const double *>(d_T);
-      a.cost = c->mma_f;
-      a.grad = c->mma_g;
-      a.B = B; a.m = m; a.t_stride = time_stride;
-      while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(double)) > 64 * 1024) --tpb;
-      a.tpb = tpb;
       HIPCHK(c, gtop_launch_eval_mma(a, st, waves, spl, c->prm.enable_dyn != 0, 1 << 20, s));
     } else {
       if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s,

@@ -44,6 +44,13 @@ struct GtopMmaState {
   // grad_traj_optimizer.cpp:144-148); 0 = off.  max_ticks: wall clock in ticks of the 100 MHz device clock.
   double ftol_rel, xtol_rel;
   long long max_ticks;
+  // The one-launch loop of gtop_eval_wave_kernel can do without the launches around it (all optional, NULL = off):
+  // x0_init: start points [B][n] — the state is initialised in the kernel (mma_init_kernel's arithmetic) instead of
+  // being loaded; out_*: where the results go when the loop ends (the best point, its cost, the nlopt_result-style
+  // code and the evaluations used: what the copies and mma_finish_kernel deliver otherwise).
+  const double *x0_init;
+  double *out_x, *out_minf;
+  int *out_code, *out_nevals;
 };
 enum { GTOP_MMA_FTOL_REACHED = 3, GTOP_MMA_XTOL_REACHED = 4, GTOP_MMA_MAXEVAL_REACHED = 5, GTOP_MMA_MAXTIME_REACHED = 6 };
 // red_rows: rows of the reduction tile (0 = the full 19; the launcher passes what the kernel variant uses)
@@ -81,6 +88,9 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
                                   double *dist, float *dist32, hipStream_t stream);
 
 // fused: cost/gradient at st.xcur + MMA update in one launch (fp64; spl must be 1, 3 or 6)
+// true when gtop_launch_eval_mma with these arguments runs the one-launch loop of gtop_eval_wave_kernel (which
+// honours st.x0_init / st.out_*); the other bodies need the state initialised and the results collected around them
+bool gtop_eval_mma_is_wave_loop(const GtopKernelArgs<double> &args, int waves, int spl, bool dyn, int max_blocks);
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
                                 bool dyn, int max_blocks, hipStream_t stream);
 hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const double *x0, hipStream_t stream);

@@ -1195,8 +1195,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   }
   // The optimizer loop keeps its trajectory's state on the chip between passes: the eight n-vectors in LDS (behind
   // the tile and the gradient rows; n <= 45 < 64, lane j owns entry j) and the scalars in registers; global memory
-  // sees the trial point of every pass (the evaluation reads its inputs from there) and everything else once, at
-  // the end.  With the state in global memory every pass paid five dependent round trips for it — 7 us per pass,
+  // sees it once, at the end.  With the state in global memory every pass paid five dependent round trips for it — 7 us per pass,
   // of which the evaluation is 2.5.
   [[maybe_unused]] double *mv = nullptr;   // [8][64]: x, xcur, xprev, xprevprev, dfdx, sigma, lb, ub
   [[maybe_unused]] GtopMmaVecs mvecs = {};
@@ -1204,12 +1203,28 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   [[maybe_unused]] bool mma_live = false;
   if constexpr (MMA) {
     mv = reinterpret_cast<double *>(tile) + kRedVals * kStride + 128;
-    mvecs = GtopMmaVecs{mv, mv + 64, mv + 128, mv + 192, mv + 256, mv + 320, mv + 384, mv + 448,
-                        st.xcur + (size_t)b0 * n};
+    // (the evaluation reads its inputs from here too — the trial point, and Df and T staged once behind the
+    // vectors — so a pass has no global load but the distance-field corners, and no global store at all)
+    mvecs = GtopMmaVecs{mv, mv + 64, mv + 128, mv + 192, mv + 256, mv + 320, mv + 384, mv + 448, mv + 64};
     mma_live = grp_ok;
     if (mma_live) {
-      msc = gtop_mma_load_scalars(st, b0);
       const size_t o = (size_t)b0 * n;
+      if (lane < 18) mv[512 + lane] = a.Df[(size_t)b0 * 18 + lane];
+      if (lane < m) mv[512 + 18 + lane] = a.T[(size_t)b0 * a.t_stride + lane];
+      if (st.x0_init) {   // (uniform) a fresh problem: mma_init_kernel's arithmetic, straight into LDS
+        msc = GtopMmaScalars{1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0};
+        if (lane < n) {
+          const double lo = st.lb[o + lane], hi = st.ub[o + lane];
+          double v = st.x0_init[o + lane];
+          v = v < lo ? lo : (v > hi ? hi : v);   // nlopt clamps the start into the box
+          mv[lane] = v; mv[64 + lane] = v; mv[128 + lane] = v; mv[192 + lane] = v;
+          mv[256 + lane] = 0.0;
+          mv[320 + lane] = (isinf(lo) || isinf(hi)) ? 1.0 : 0.5 * (hi - lo);
+          mv[384 + lane] = lo;
+          mv[448 + lane] = hi;
+        }
+      } else {
+      msc = gtop_mma_load_scalars(st, b0);
       if (lane < n) {
         mv[lane] = st.x[o + lane];
         mv[64 + lane] = st.xcur[o + lane];
@@ -1220,7 +1235,10 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         mv[384 + lane] = st.lb[o + lane];
         mv[448 + lane] = st.ub[o + lane];
       }
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // staged by some lanes, read by others of this wavefront
+    __builtin_amdgcn_wave_barrier();
   }
   for (int pass = 0; pass < npass; ++pass) {
   const R *xsrc = a.x;
@@ -1232,13 +1250,18 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       msc.state = GTOP_MMA_MAXTIME_REACHED;
       break;
     }
-    xsrc = reinterpret_cast<const R *>(st.xcur);   // (not the __restrict__ argument: the update below rewrites it)
   }
-  // ---- inputs: two waypoints' (p, v, a) per axis and T_s, straight from HBM/L2 ----
+  // ---- inputs: two waypoints' (p, v, a) per axis and T_s, straight from HBM/L2 (the optimizer loop: from LDS) ----
   // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
   const R *xb = xsrc + (size_t)b0 * n + tl * n;      // this lane's trajectory (b0: wave-uniform)
   const R *dfb = a.Df + (size_t)b0 * 18 + tl * 18;
-  const R T = a.T[(size_t)b0 * a.t_stride + tl * a.t_stride + s];
+  const R *Tb = a.T + (size_t)b0 * a.t_stride + tl * a.t_stride;
+  if constexpr (MMA) {
+    xb = reinterpret_cast<const R *>(mv + 64);
+    dfb = reinterpret_cast<const R *>(mv + 512);
+    Tb = reinterpret_cast<const R *>(mv + 512 + 18);
+  }
+  const R T = Tb[s];
   // axis 0: the (p, v, a) triple at the segment's start and at its end; the other axes are one per-lane stride
   // further (6 within Df, 3m-3 within x: :182-187)
   const bool first = s == 0, last = s + 1 == m;
@@ -1581,18 +1604,26 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
 #endif
   }   // pass
   if constexpr (MMA) {
-    if (mma_live) {   // the state goes home (xcur is there already)
+    if (mma_live) {   // the state goes home
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const size_t o = (size_t)b0 * n;
       if (lane < n) {
         st.x[o + lane] = mv[lane];
+        st.xcur[o + lane] = mv[64 + lane];
         st.xprev[o + lane] = mv[128 + lane];
         st.xprevprev[o + lane] = mv[192 + lane];
         st.dfdx[o + lane] = mv[256 + lane];
         st.sigma[o + lane] = mv[320 + lane];
       }
       if (lane == 0) gtop_mma_store_scalars(st, b0, msc);
+      // the results, where the caller wants them (otherwise: copies + mma_finish_kernel after this launch)
+      if (st.out_x && lane < n) st.out_x[o + lane] = mv[lane];
+      if (lane == 0) {
+        if (st.out_minf) st.out_minf[b0] = msc.minf;
+        if (st.out_code) st.out_code[b0] = msc.state >= 3 ? msc.state : GTOP_MMA_MAXEVAL_REACHED;
+        if (st.out_nevals) st.out_nevals[b0] = msc.nevals;
+      }
     }
   }
 }
@@ -1613,15 +1644,25 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
   return (unsigned long long)nx * ny < (1ull << 24) && nz < (1 << 24) && (nvox + 2) * elem < (1ull << 32);
 }
 
+#ifndef GTOP_WAVE_KERNEL
+#define GTOP_WAVE_KERNEL 1
+#endif
+#define GTOP_WAVE_KERNEL_DEFAULT GTOP_WAVE_KERNEL
+
+// the specialised straight-line bodies: one wavefront = one whole trajectory (SPL 3 or 6) or two (SPL 6)
+template <typename R>
+static bool gtop_fixed_body_ok(const GtopKernelArgs<R> &args, int waves, int spl, int grid) {
+  const int groups = (args.B + args.tpb - 1) / args.tpb;
+  return (spl == 3 || spl == 6) && waves == 1 && args.m >= 2 &&
+         args.tpb * args.m <= gtop_eval_segments_per_wave(spl) &&
+         grid == 8 * ((groups + 7) / 8);   // (no grid-stride loop in those bodies)
+}
+
 template <typename R, bool DYN, bool MMA, bool WIDE>
 static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, int grid,
                              size_t smem /* of the generic body */, hipStream_t stream, bool wave_ok) {
   void (*kern)(const GtopKernelArgs<R>, const GtopMmaState) = nullptr;
-  // the specialised straight-line bodies: one wavefront = one whole trajectory (SPL 3 or 6) or two (SPL 6)
-  const int groups = (args.B + args.tpb - 1) / args.tpb;
-  const bool fixed_ok = (spl == 3 || spl == 6) && waves == 1 && args.m >= 2 &&
-                        args.tpb * args.m <= gtop_eval_segments_per_wave(spl) &&
-                        grid == 8 * ((groups + 7) / 8);   // (no grid-stride loop in those bodies)
+  const bool fixed_ok = gtop_fixed_body_ok(args, waves, spl, grid);
   // A field that outgrows the 256 MB Infinity Cache is served by HBM; a fourth wavefront per SIMD then only
   // adds L2 misses (measured at 400^3 fp64, m = 12: 47 us with the generic three-wavefront body, 52 us with
   // four, 50 us with the specialised body held at three), so the SPL = 6 specialisations are for resident fields.
@@ -1631,9 +1672,7 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
   const bool two = fixed_ok && args.tpb == 2 && spl == 6 && !MMA && resident;
   if (!MMA && spl == 6 && (one || two))   // their tile
     smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R), red_chunk(sizeof(R), 6, args.tpb));
-#ifndef GTOP_WAVE_KERNEL
-#define GTOP_WAVE_KERNEL 1
-#endif
+
 #ifndef GTOP_WAVE_MINW3_FROM
 #define GTOP_WAVE_MINW3_FROM 3072   // batches that put a third wavefront on a SIMD (1 024 SIMDs)
 #endif
@@ -1652,8 +1691,8 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
     // (64-bit field indices — fields past 4 GiB — cost the 168-VGPR fp64 body 14 spilled registers: those stay on
     // the two-wavefront budget)
     const bool three = args.B >= GTOP_WAVE_MINW3_FROM && !(WIDE && sizeof(R) == 8);
-    // tile + the optimizer's gradient rows (+ its state: 8 vectors of 64, gtop_eval_wave_kernel)
-    const size_t wsmem = (kRedVals * red_stride(spl) + 128 + (MMA ? 512 : 0)) * sizeof(R);
+    // tile + the optimizer's gradient rows (+ its state: 8 vectors of 64, Df, T; gtop_eval_wave_kernel)
+    const size_t wsmem = (kRedVals * red_stride(spl) + 128 + (MMA ? 512 + 32 : 0)) * sizeof(R);
     if constexpr (MMA) {
       if constexpr (sizeof(R) == 8) {
         if (one && spl == 3) {
@@ -1736,6 +1775,14 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, b
                             int max_blocks, hipStream_t stream, bool wave_kernel_ok) {
   const GtopMmaState none{};
   return launch_any<R, false>(args, none, waves, spl, dyn, max_blocks, stream, wave_kernel_ok);
+}
+
+bool gtop_eval_mma_is_wave_loop(const GtopKernelArgs<double> &args, int waves, int spl, bool dyn, int max_blocks) {
+  if (args.B <= 0 || dyn || !GTOP_WAVE_KERNEL_DEFAULT) return false;
+  const int groups = (args.B + args.tpb - 1) / args.tpb;
+  const int vblocks = 8 * ((groups + 7) / 8);
+  const int grid = vblocks < max_blocks ? vblocks : max_blocks;
+  return gtop_fixed_body_ok(args, waves, spl, grid) && args.tpb == 1 && spl == 3;   // launch_spl: `one && spl == 3`
 }
 
 // cost/gradient at st.xcur + the MMA update, one launch (fp64; spl 1, 3 or 6)
