@@ -97,7 +97,7 @@ int fail(gtop_ctx *c, int code, const std::string &msg) {
       return fail(ctx, GTOP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-constexpr size_t kPollDoubles = 1024;                    // outputs per call the completion poll scans (B <= 22 at m = 6)
+constexpr size_t kPollDoubles = 16384;                   // outputs per call the completion poll scans (B <= 356 at m = 6)
 constexpr uint64_t kPollSentinel = 0x7ff8dead5eed0badull;   // a quiet NaN with a payload the hardware never generates
 constexpr double kPollSeconds = 2e-3;
 constexpr size_t kZeroCopyDoubles = 1u << 17;   // (measured: 2x faster at B = 1, 1.5x at B = 1024, on par at B = 4096 x 45)

@@ -140,8 +140,8 @@ int gtop_get_problem(gtop_ctx *ctx, double *segment_time, double *Df);
 /* Batched form of GradTrajOptimizer::costFunc / getCostAndGradient
  * (src/grad_traj_optimizer.cpp:554-562, :281-448) for the problem set by
  * gtop_set_problem: x, grad are B*n host doubles, cost B host doubles.
- * fp64 on the device; includes the PCIe copies.  Small batches (up to 1024
- * outputs, i.e. the NLopt callback) are read from and written to pinned host
+ * fp64 on the device; includes the PCIe copies.  Small batches (up to 16384
+ * outputs: the NLopt callback, a rendezvous generation) are read from and written to pinned host
  * memory by the kernel itself, and the call returns when the last output has
  * landed there (each is stored once; the slots are preset to a NaN pattern no
  * evaluation produces).  GTOP_POLL_COMPLETION=0 in the environment at

@@ -70,7 +70,7 @@ def test_small_host_batches_complete_by_polling_or_by_stream_wait(scene, gtop, m
         c.update_sdf_map(mp.obstacle_points())
         c.set_params()
         ctxs[mode] = c
-    for B in (1, 7, 22, 23, 300, 4000):                         # 22 x 46 outputs = the last polled size at m = 6
+    for B in (1, 7, 64, 356, 357, 4000):                        # 356 x 46 outputs = the last polled size at m = 6
         b = problem.make_trajectories(B, 6, mp, seed=70 + B)
         res = []
         for mode in ("1", "0"):
