@@ -61,9 +61,19 @@ setup_paths_kernel(int B, int m, const double *__restrict__ wp, double mean_v, d
 
 // value of sum_j c[j] t^j the way PolynomialTraj::evaluate forms it
 // (polynomial_traj.hpp:57-66): tv(order-1-i) = pow(t, i), pt = tv . c_descending
+// The powers by multiplication: pow(t, i) for i <= 5 is the correctly rounded t^i on the host and 1-2 ulp off
+// that in a product chain (the device's pow() is itself only within an ulp), far inside the 1e-9 the points are
+// held to — and a twelfth of the instructions: 18 pow() calls were ~95 % of this kernel (176 -> 31 us for 1 024
+// trajectories / 538 k samples).
 __device__ __forceinline__ double poly_eval(const double *c, double t) {
+  const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
   double s = 0.0;
-  for (int i = 5; i >= 0; --i) s += pow(t, (double)i) * c[i];   // dot over descending powers: t^5 c5 first
+  s += t5 * c[5];   // dot over descending powers: t^5 c5 first
+  s += t4 * c[4];
+  s += t3 * c[3];
+  s += t2 * c[2];
+  s += t * c[1];
+  s += c[0];        // pow(t, 0) = 1
   return s;
 }
 
@@ -72,7 +82,7 @@ __device__ __forceinline__ double poly_eval(const double *c, double t) {
 //   * getTraj / getLength (:69-92): the samples every dt_sample are spread over the lanes, 64 at a time.  The
 //     reference accumulates the sample time (eval_t += 0.01) and tests eval_t <= time_sum, so the time of sample
 //     k is that sum, not k*dt: every chunk starts from the carried accumulated value and lane l adds dt l times
-//     (64 predicated additions per chunk, nothing next to the 18 pow() of a sample) — sample count and sample
+//     (64 predicated additions per chunk) — sample count and sample
 //     times are the reference's exactly.  A lane's neighbour's point arrives through a wavefront shuffle, the
 //     previous chunk's last point through a broadcast; the length is a wavefront sum (summation order differs from
 //     the serial sum: ~1e-16).
@@ -81,7 +91,7 @@ __device__ __forceinline__ double poly_eval(const double *c, double t) {
 //     segment's end-point value, counted once per accumulated eval_t < ts.
 // samples (may be NULL): [B][max_samples][3], the getTraj points; stats[8] = their number (also when it exceeds
 // max_samples: then only the first max_samples are stored).
-// Bound: VALU (the pow() calls, kept for 1e-9 agreement with the reference's evaluation order); 24 B per sample out.
+// Bound: VALU (the accumulated sample times: 63 dependent additions per chunk); 24 B per sample out.
 __global__ void __launch_bounds__(64)
 eval_trajectories_kernel(int B, int m, const double *__restrict__ coeff, const double *__restrict__ T,
                          int t_stride, double dt_sample, double *__restrict__ out /*[B][GTOP_TRAJ_STATS]*/,
@@ -146,6 +156,7 @@ eval_trajectories_kernel(int B, int m, const double *__restrict__ coeff, const d
     int c = 0;
     if (s < m) {
       const double Ts = ts[s];
+      const double Tp[6] = {1.0, Ts, Ts * Ts, Ts * Ts * Ts, (Ts * Ts) * (Ts * Ts), (Ts * Ts) * (Ts * Ts) * Ts};   // pow(Ts, i)
       // getAccCost (:96-109): um = 2 * (coefficient of t^2) = a(0) per segment
       const double ux = 2 * cf[s * 18 + 2], uy = 2 * cf[s * 18 + 8], uz = 2 * cf[s * 18 + 14];
       ac = (ux * ux + uy * uy + uz * uz) * Ts;
@@ -157,7 +168,7 @@ eval_trajectories_kernel(int B, int m, const double *__restrict__ coeff, const d
           double col = 0.0;
           for (int i = 3; i < 6; ++i) {
             const double di = i, dj = j;
-            col += cc[i] * (di * (di - 1) * (di - 2) * dj * (dj - 1) * (dj - 2) * pow(Ts, di + dj - 5) / (di + dj - 5));
+            col += cc[i] * (di * (di - 1) * (di - 2) * dj * (dj - 1) * (dj - 2) * Tp[i + j - 5] / (di + dj - 5));
           }
           acc += col * cc[j];
         }
@@ -168,8 +179,8 @@ eval_trajectories_kernel(int B, int m, const double *__restrict__ coeff, const d
       for (int a = 0; a < 3; ++a) {
         const double *cc = cf + s * 18 + 6 * a;
         double sv = 0.0, sa = 0.0;
-        for (int i = 0; i < 5; ++i) sv += pow(Ts, (double)i) * ((double)(i + 1) * cc[i + 1]);
-        for (int i = 0; i < 4; ++i) sa += pow(Ts, (double)i) * ((double)((i + 2) * (i + 1)) * cc[i + 2]);
+        for (int i = 0; i < 5; ++i) sv += Tp[i] * ((double)(i + 1) * cc[i + 1]);
+        for (int i = 0; i < 4; ++i) sa += Tp[i] * ((double)((i + 2) * (i + 1)) * cc[i + 2]);
         vel[a] = sv;
         acc3[a] = sa;
       }
