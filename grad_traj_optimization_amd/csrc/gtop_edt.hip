@@ -91,6 +91,15 @@ edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, c
   }
   // min over the boxes (edt_environment.cpp:26-73): at the 8 corner centres (:96-98), or at the position (:131)
   double dbox = 10000000.0;   // :64
+  double vmax = 0.0;          // the largest of the 8 corner values so far
+  if constexpr (!COARSE) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int z = 0; z < 2; ++z) vmax = fmax(vmax, values[x][y][z]);
+  }
   for (int b0 = 0; b0 < nbox; b0 += kBoxChunk) {
     const int nb = min(kBoxChunk, nbox - b0);
     __syncthreads();
@@ -124,15 +133,28 @@ edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, c
               const double pt = (idx[k] + o + 0.5) * g.res + g.origin[k];
               d1[k][o] = (pt >= bmin[k] && pt <= bmax[k]) ? 0.0 : fmin(fabs(pt - bmin[k]), fabs(pt - bmax[k]));
             }
+          // The corner nearest to the box takes, per axis, the smaller of the two offsets' distances, and its
+          // distance is the same floating-point expression as in the loop below; every other corner's is no
+          // smaller (sums of non-negative terms and sqrt round monotonically).  A box that does not undercut the
+          // LARGEST of the 8 current values there cannot change any of them: skipped, bit for bit the same result —
+          // with a few dozen boxes in a map most are far from a query (2^20 queries, 32 boxes: 323 -> 211 us; a
+          // wavefront still pays for a box any of its 64 queries is near).
+          const double near2 = fmin(d1[0][0], d1[0][1]) * fmin(d1[0][0], d1[0][1]) +
+                               fmin(d1[1][0], d1[1][1]) * fmin(d1[1][0], d1[1][1]) +
+                               fmin(d1[2][0], d1[2][1]) * fmin(d1[2][0], d1[2][1]);
+          if (sqrt(near2) < vmax) {
+            vmax = 0.0;
 #pragma unroll
-          for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
+              for (int y = 0; y < 2; ++y)
 #pragma unroll
-              for (int z = 0; z < 2; ++z) {
-                const double d2 = sqrt(d1[0][x] * d1[0][x] + d1[1][y] * d1[1][y] + d1[2][z] * d1[2][z]);   // dist.norm()
-                values[x][y][z] = d2 < values[x][y][z] ? d2 : values[x][y][z];
-              }
+                for (int z = 0; z < 2; ++z) {
+                  const double d2 = sqrt(d1[0][x] * d1[0][x] + d1[1][y] * d1[1][y] + d1[2][z] * d1[2][z]);   // dist.norm()
+                  values[x][y][z] = d2 < values[x][y][z] ? d2 : values[x][y][z];
+                  vmax = fmax(vmax, values[x][y][z]);
+                }
+          }
         }
       }
     }
