@@ -801,8 +801,10 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   st.out_code = st.out_nevals = nullptr;
   int waves, spl, tpb;
   // whole loop in one launch: the unrolled one-trajectory-per-wavefront body wins at every batch
-  // size (measured 1024 ... 16384, tools/opt_time.py); otherwise the evaluation kernel's own rule
-  launch_geometry(c, B, m, &waves, &spl, &tpb, c->fuse_mma == 2 ? c->auto_spl_small : 0);
+  // size (measured 1024 ... 16384, tools/opt_time.py) — 10 lanes per segment up to 6 segments, 5 lanes per
+  // segment up to 12; otherwise the evaluation kernel's own rule
+  launch_geometry(c, B, m, &waves, &spl, &tpb,
+                  c->fuse_mma == 2 ? ((m > 6 && m <= 12) ? c->auto_spl_large : c->auto_spl_small) : 0);
   const bool fused = c->fuse_mma != 0 && (spl == 1 || spl == 3 || spl == 6);
   const bool resident = fused && c->fuse_mma == 2;   // one launch runs all max_evals evaluations of every trajectory
   st.iters = resident ? max_evals : 1;

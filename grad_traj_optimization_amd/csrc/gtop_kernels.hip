@@ -1139,9 +1139,13 @@ struct GtopWaveConsts {
 // reject, asymptotes, stop rules, next trial point), evaluate again; cost and gradient never leave the chip.  One
 // wavefront owns the trajectory, so the loop needs no barrier at all.  MM = GtopNoMma: a plain evaluation.
 struct GtopNoMma {};
+// register budget (wavefronts per SIMD) of a variant: MINW, except that the optimizer loop on six samples per lane
+// keeps the one-sample-at-a-time structure of MINW = 3 on the two-wavefront budget (its update needs the room)
+template <typename MM, int SPL, int MINW>
+constexpr int gtop_wave_budget() { return (!std::is_same<MM, GtopNoMma>::value && SPL == 6) ? 2 : MINW; }
 
 template <typename R, bool WIDE, int SPL, int NT, bool COLLI, int MINW, typename MM = GtopNoMma>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MINW)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(gtop_wave_budget<MM, SPL, MINW>())))
 gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df, const R *__restrict__ arg_T,
                       const R *__restrict__ arg_sdf, int arg_B, int arg_m, int arg_t_stride, int arg_nx, int arg_ny,
                       int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K, const MM st) {
@@ -1154,8 +1158,10 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   constexpr int LPS = kSamples / SPL;   // lanes per segment
   constexpr int SPW = 64 / LPS;         // segment slots per wavefront
   constexpr int kStride = red_stride(SPL);
+  constexpr int kMV = SPL == 6 ? 128 : 64;   // rows of the optimizer loop's LDS vectors: n <= 45 resp. 99 variables
   static_assert(SPL == 3 || SPL == 6, "10 or 5 lanes per segment");
   static_assert(SPL == 3 || MINW >= 3, "six samples per lane: one (pair) at a time only");
+  static_assert(!MMA || SPL == 3 || !WIDE, "the six-samples-per-lane optimizer loop: 32-bit field offsets");
   static_assert(NT == 1 || NT == 2, "one or two trajectories per wavefront");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);   // [19][kStride] (+ [kRounds*64] gradient for the optimizer update)
@@ -1197,7 +1203,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // the tile and the gradient rows; n <= 45 < 64, lane j owns entry j) and the scalars in registers; global memory
   // sees it once, at the end.  With the state in global memory every pass paid five dependent round trips for it — 7 us per pass,
   // of which the evaluation is 2.5.
-  [[maybe_unused]] double *mv = nullptr;   // [8][64]: x, xcur, xprev, xprevprev, dfdx, sigma, lb, ub
+  [[maybe_unused]] double *mv = nullptr;   // [8][kMV]: x, xcur, xprev, xprevprev, dfdx, sigma, lb, ub; then Df, T
   [[maybe_unused]] GtopMmaVecs mvecs = {};
   [[maybe_unused]] GtopMmaScalars msc = {};
   [[maybe_unused]] bool mma_live = false;
@@ -1205,35 +1211,36 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     mv = reinterpret_cast<double *>(tile) + kRedVals * kStride + 128;
     // (the evaluation reads its inputs from here too — the trial point, and Df and T staged once behind the
     // vectors — so a pass has no global load but the distance-field corners, and no global store at all)
-    mvecs = GtopMmaVecs{mv, mv + 64, mv + 128, mv + 192, mv + 256, mv + 320, mv + 384, mv + 448, mv + 64};
+    mvecs = GtopMmaVecs{mv, mv + kMV, mv + 2 * kMV, mv + 3 * kMV, mv + 4 * kMV, mv + 5 * kMV, mv + 6 * kMV, mv + 7 * kMV,
+                        mv + kMV};
     mma_live = grp_ok;
     if (mma_live) {
       const size_t o = (size_t)b0 * n;
-      if (lane < 18) mv[512 + lane] = a.Df[(size_t)b0 * 18 + lane];
-      if (lane < m) mv[512 + 18 + lane] = a.T[(size_t)b0 * a.t_stride + lane];
+      if (lane < 18) mv[8 * kMV + lane] = a.Df[(size_t)b0 * 18 + lane];
+      if (lane < m) mv[8 * kMV + 18 + lane] = a.T[(size_t)b0 * a.t_stride + lane];
       if (st.x0_init) {   // (uniform) a fresh problem: mma_init_kernel's arithmetic, straight into LDS
         msc = GtopMmaScalars{1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0};
-        if (lane < n) {
-          const double lo = st.lb[o + lane], hi = st.ub[o + lane];
-          double v = st.x0_init[o + lane];
+        for (int j = lane; j < n; j += 64) {
+          const double lo = st.lb[o + j], hi = st.ub[o + j];
+          double v = st.x0_init[o + j];
           v = v < lo ? lo : (v > hi ? hi : v);   // nlopt clamps the start into the box
-          mv[lane] = v; mv[64 + lane] = v; mv[128 + lane] = v; mv[192 + lane] = v;
-          mv[256 + lane] = 0.0;
-          mv[320 + lane] = (isinf(lo) || isinf(hi)) ? 1.0 : 0.5 * (hi - lo);
-          mv[384 + lane] = lo;
-          mv[448 + lane] = hi;
+          mv[j] = v; mv[kMV + j] = v; mv[2 * kMV + j] = v; mv[3 * kMV + j] = v;
+          mv[4 * kMV + j] = 0.0;
+          mv[5 * kMV + j] = (isinf(lo) || isinf(hi)) ? 1.0 : 0.5 * (hi - lo);
+          mv[6 * kMV + j] = lo;
+          mv[7 * kMV + j] = hi;
         }
       } else {
       msc = gtop_mma_load_scalars(st, b0);
-      if (lane < n) {
-        mv[lane] = st.x[o + lane];
-        mv[64 + lane] = st.xcur[o + lane];
-        mv[128 + lane] = st.xprev[o + lane];
-        mv[192 + lane] = st.xprevprev[o + lane];
-        mv[256 + lane] = st.dfdx[o + lane];
-        mv[320 + lane] = st.sigma[o + lane];
-        mv[384 + lane] = st.lb[o + lane];
-        mv[448 + lane] = st.ub[o + lane];
+      for (int j = lane; j < n; j += 64) {
+        mv[j] = st.x[o + j];
+        mv[kMV + j] = st.xcur[o + j];
+        mv[2 * kMV + j] = st.xprev[o + j];
+        mv[3 * kMV + j] = st.xprevprev[o + j];
+        mv[4 * kMV + j] = st.dfdx[o + j];
+        mv[5 * kMV + j] = st.sigma[o + j];
+        mv[6 * kMV + j] = st.lb[o + j];
+        mv[7 * kMV + j] = st.ub[o + j];
       }
       }
     }
@@ -1257,9 +1264,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   const R *dfb = a.Df + (size_t)b0 * 18 + tl * 18;
   const R *Tb = a.T + (size_t)b0 * a.t_stride + tl * a.t_stride;
   if constexpr (MMA) {
-    xb = reinterpret_cast<const R *>(mv + 64);
-    dfb = reinterpret_cast<const R *>(mv + 512);
-    Tb = reinterpret_cast<const R *>(mv + 512 + 18);
+    xb = reinterpret_cast<const R *>(mv + kMV);
+    dfb = reinterpret_cast<const R *>(mv + 8 * kMV);
+    Tb = reinterpret_cast<const R *>(mv + 8 * kMV + 18);
   }
   const R T = Tb[s];
   // axis 0: the (p, v, a) triple at the segment's start and at its end; the other axes are one per-lane stride
@@ -1579,14 +1586,16 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     if constexpr (NT == 2) {
       if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
       if (grp_ok & (lane == 63) & (b0 + 1 < a.B)) a.cost[b0 + 1] = cpart + (R)1e-3;
-    } else if constexpr (SPW > 8) {
+    } else if constexpr (SPW > 8 && !MMA) {
       cpart += gtop_dpp_move<0x118>(cpart);   // row_shr:8 -> lane 63 holds lanes 48..63 (up to 12 segments)
       if (grp_ok & (lane == 63)) a.cost[b0] = cpart + (R)1e-3;
     } else if constexpr (MMA) {
       // f(xcur) to every lane, then this wavefront's optimizer step for its trajectory
+      constexpr int kCostLane = SPW > 8 ? 63 : 55;
+      if constexpr (SPW > 8) cpart += gtop_dpp_move<0x118>(cpart);   // row_shr:8 (up to 12 segments)
       const unsigned long long u = __builtin_bit_cast(unsigned long long, (double)(cpart + (R)1e-3));
-      const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 55);
-      const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 55);
+      const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, kCostLane);
+      const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), kCostLane);
       const double fcur = __builtin_bit_cast(double, ((unsigned long long)hi32 << 32) | lo32);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
       __builtin_amdgcn_wave_barrier();
@@ -1608,17 +1617,18 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const size_t o = (size_t)b0 * n;
-      if (lane < n) {
-        st.x[o + lane] = mv[lane];
-        st.xcur[o + lane] = mv[64 + lane];
-        st.xprev[o + lane] = mv[128 + lane];
-        st.xprevprev[o + lane] = mv[192 + lane];
-        st.dfdx[o + lane] = mv[256 + lane];
-        st.sigma[o + lane] = mv[320 + lane];
+      for (int j = lane; j < n; j += 64) {
+        st.x[o + j] = mv[j];
+        st.xcur[o + j] = mv[kMV + j];
+        st.xprev[o + j] = mv[2 * kMV + j];
+        st.xprevprev[o + j] = mv[3 * kMV + j];
+        st.dfdx[o + j] = mv[4 * kMV + j];
+        st.sigma[o + j] = mv[5 * kMV + j];
       }
       if (lane == 0) gtop_mma_store_scalars(st, b0, msc);
       // the results, where the caller wants them (otherwise: copies + mma_finish_kernel after this launch)
-      if (st.out_x && lane < n) st.out_x[o + lane] = mv[lane];
+      if (st.out_x)
+        for (int j = lane; j < n; j += 64) st.out_x[o + j] = mv[j];
       if (lane == 0) {
         if (st.out_minf) st.out_minf[b0] = msc.minf;
         if (st.out_code) st.out_code[b0] = msc.state >= 3 ? msc.state : GTOP_MMA_MAXEVAL_REACHED;
@@ -1648,6 +1658,10 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 #define GTOP_WAVE_KERNEL 1
 #endif
 #define GTOP_WAVE_KERNEL_DEFAULT GTOP_WAVE_KERNEL
+#ifndef GTOP_WAVE_SPL6
+#define GTOP_WAVE_SPL6 1
+#endif
+#define GTOP_WAVE_SPL6_DEFAULT GTOP_WAVE_SPL6
 
 // the specialised straight-line bodies: one wavefront = one whole trajectory (SPL 3 or 6) or two (SPL 6)
 template <typename R>
@@ -1676,9 +1690,7 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
 #ifndef GTOP_WAVE_MINW3_FROM
 #define GTOP_WAVE_MINW3_FROM 3072   // batches that put a third wavefront on a SIMD (1 024 SIMDs)
 #endif
-#ifndef GTOP_WAVE_SPL6
-#define GTOP_WAVE_SPL6 1
-#endif
+
   if constexpr (GTOP_WAVE_KERNEL && !DYN) {
     // gtop_eval_wave_kernel: whole trajectories per wavefront, no workgroup barrier.  spl 3: one trajectory of up to
     // 6 segments (latency variant below GTOP_WAVE_MINW3_FROM trajectories) — with or without the optimizer loop;
@@ -1692,7 +1704,7 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
     // the two-wavefront budget)
     const bool three = args.B >= GTOP_WAVE_MINW3_FROM && !(WIDE && sizeof(R) == 8);
     // tile + the optimizer's gradient rows (+ its state: 8 vectors of 64, Df, T; gtop_eval_wave_kernel)
-    const size_t wsmem = (kRedVals * red_stride(spl) + 128 + (MMA ? 512 + 32 : 0)) * sizeof(R);
+    const size_t wsmem = (kRedVals * red_stride(spl) + 128 + (MMA ? 8 * (spl == 6 ? 128 : 64) + 32 : 0)) * sizeof(R);
     if constexpr (MMA) {
       if constexpr (sizeof(R) == 8) {
         if (one && spl == 3) {
@@ -1702,6 +1714,16 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
           hipLaunchKernelGGL(wk, dim3(grid), dim3(64), wsmem, stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B, wa.m, wa.t_stride,
                              wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{}, st);
           return hipGetLastError();
+        }
+        if constexpr (!WIDE) {
+          if (GTOP_WAVE_SPL6 && fixed_ok && spl == 6 && args.tpb == 1) {
+            // 7 .. 12 segments: one trajectory per wavefront at five lanes per segment, one sample at a time
+            auto wk = colli ? gtop_eval_wave_kernel<R, false, 6, 1, true, 3, GtopMmaState>
+                            : gtop_eval_wave_kernel<R, false, 6, 1, false, 3, GtopMmaState>;
+            hipLaunchKernelGGL(wk, dim3(grid), dim3(64), wsmem, stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B, wa.m,
+                               wa.t_stride, wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{}, st);
+            return hipGetLastError();
+          }
         }
       }
     } else {
@@ -1782,7 +1804,9 @@ bool gtop_eval_mma_is_wave_loop(const GtopKernelArgs<double> &args, int waves, i
   const int groups = (args.B + args.tpb - 1) / args.tpb;
   const int vblocks = 8 * ((groups + 7) / 8);
   const int grid = vblocks < max_blocks ? vblocks : max_blocks;
-  return gtop_fixed_body_ok(args, waves, spl, grid) && args.tpb == 1 && spl == 3;   // launch_spl: `one && spl == 3`
+  // launch_spl: `one && spl == 3`, or the six-samples-per-lane loop (32-bit field offsets only)
+  if (!gtop_fixed_body_ok(args, waves, spl, grid) || args.tpb != 1) return false;
+  return spl == 3 || (GTOP_WAVE_SPL6_DEFAULT && spl == 6 && gtop_field_is_narrow(args.nx, args.ny, args.nz, sizeof(double)));
 }
 
 // cost/gradient at st.xcur + the MMA update, one launch (fp64; spl 1, 3 or 6)

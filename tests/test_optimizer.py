@@ -112,6 +112,8 @@ def test_default_bounds(gtop):
 
 
 @pytest.mark.parametrize("m,evals,kw", [(6, 25, {}), (3, 40, {}),
+                                        (9, 20, {}), (12, 15, {}),      # the five-lanes-per-segment loop (7..12 segments)
+                                        (13, 12, {}),                    # past it: the generic body
                                         (6, 20, dict(enable_dyn=1, alpha_v=2.0, alpha_a=1.5))])   # MMA + DYN bodies
 def test_device_lockstep_mma_follows_the_serial_algorithm(scene, oracle_mod, gtop, m, evals, kw):
     mp, ctx, sdf = scene
