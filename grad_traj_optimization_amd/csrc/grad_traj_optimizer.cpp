@@ -220,8 +220,17 @@ bool GradTrajOptimizer::optimizeTrajectory(int step) {
   }
   std::vector<double> x = dp_;   // :182-187
   gtop_clear_cost_curve(ctx_);   // :192-194
-  MmaResult r = mma_minimize(n, nlopt_trampoline, ctx_, lb.data(), ub.data(), x.data(), opt);
-  last_evals_ = r.nevals;
+  if (cfg_.optimize_on_device) {
+    // (maxtime alone bounds the reference's run: an evaluation cap far past what it can reach stands in for "none")
+    const gtop_stop stop = {opt.maxeval > 0 ? opt.maxeval : (1 << 24), 0.0, 0.0, opt.maxtime};
+    double minf = 0.0;
+    int32_t nev = 0, code = 0;
+    last_status_ = gtop_optimize_batch_ex(ctx_, 1, x.data(), lb.data(), ub.data(), &stop, &minf, &nev, &code);
+    last_evals_ = nev;
+  } else {
+    MmaResult r = mma_minimize(n, nlopt_trampoline, ctx_, lb.data(), ub.data(), x.data(), opt);
+    last_evals_ = r.nevals;
+  }
   dp_ = x;                        // :202-207
   coefficientsFromDerivatives(x);  // :230
   if (step == 1 || step == 2) {   // :233-240

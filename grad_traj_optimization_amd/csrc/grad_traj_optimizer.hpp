@@ -61,6 +61,11 @@ class GradTrajOptimizer {
     int device = 0;
     int enable_dyn = 0;
     int max_evals = 0;
+    // 0: the optimizer (csrc/mma.hpp standing in for NLopt's LD_MMA) runs on the host and calls the cost function
+    // once per evaluation, as the reference does (:195) — iter_num, total_time and the cost curve are kept per call.
+    // 1: the whole optimisation is ONE launch of the batched device optimizer (gtop_optimize_batch_ex, same
+    // algorithm, same stop rules); only the evaluation count is reported, the cost curve stays empty.
+    int optimize_on_device = 0;
   };
 
   GradTrajOptimizer();

@@ -3,6 +3,7 @@
 // EpicOne1/grad_traj_optimization): 40x40x5 m map @0.2, two walls of obstacle
 // points, 11 waypoints, one optimizeTrajectory(OPT_SECOND_STEP).
 // Prints one JSON object; tests/test_cpp_shim.py checks it against the oracle.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -21,6 +22,7 @@ int main(int argc, char **argv) {
   GradTrajOptimizer::Config cfg;   // launch/opti_node.launch:3-28 defaults
   cfg.max_evals = argc > 1 ? std::atoi(argv[1]) : 60;
   cfg.time_limit_2 = 5.0;          // evaluation-capped so the run is reproducible
+  cfg.optimize_on_device = argc > 2 ? std::atoi(argv[2]) : 0;   // 1: the whole optimisation in one launch
   GradTrajOptimizer grad_traj_opt(cfg);
   if (!grad_traj_opt.ok()) {
     std::fprintf(stderr, "GradTrajOptimizer: %s\n", grad_traj_opt.lastError());
@@ -52,7 +54,9 @@ int main(int argc, char **argv) {
   Matrix coeff0, coeff;
   std::vector<double> time_sgm;
   grad_traj_opt.getCoefficient(coeff0);
+  const auto t_opt0 = std::chrono::steady_clock::now();
   grad_traj_opt.optimizeTrajectory(OPT_SECOND_STEP);
+  const double opt_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_opt0).count();
   grad_traj_opt.getCoefficient(coeff);
   grad_traj_opt.getSegmentTime(time_sgm);
 
@@ -61,8 +65,8 @@ int main(int argc, char **argv) {
   std::vector<double> curve_c, curve_t;
   grad_traj_opt.getCostCurve(curve_c, curve_t);
 
-  std::printf("{\n\"n_obstacle_points\": %zu,\n\"evals\": %d,\n\"cost0\": %.17g,\n\"cost1\": %.17g,\n",
-              obss.size(), grad_traj_opt.iterations(), c0, c1);
+  std::printf("{\n\"n_obstacle_points\": %zu,\n\"evals\": %d,\n\"cost0\": %.17g,\n\"cost1\": %.17g,\n\"optimize_seconds\": %.6g,\n",
+              obss.size(), grad_traj_opt.iterations(), c0, c1, opt_seconds);
   print_vec("x0", x0);
   print_vec("grad0", g0);
   print_vec("x1", x1);

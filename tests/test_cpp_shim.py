@@ -66,3 +66,18 @@ def test_optimizer_improves_and_bookkeeping(run):
         for a in range(3):
             end = sum(c[s, 6 * a + j] * T[s] ** j for j in range(6))
             assert abs(end - c[s + 1, 6 * a]) <= 1e-9 * max(1.0, abs(end))
+
+
+def test_device_optimizer_option_follows_the_host_loop(run):
+    """Config::optimize_on_device: the same scene with the whole optimisation as one launch of the batched
+    device optimizer (10 segments: the five-lanes-per-segment loop).  Same algorithm, same evaluation cap:
+    the same minimum to rounding, no per-call cost curve."""
+    out = subprocess.run([DEMO, "40", "1"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    txt = out.stdout
+    dev = json.loads(txt[txt.index("{"):txt.rindex("}") + 1])
+    assert dev["evals"] == run["evals"] == 40
+    assert abs(dev["cost1"] - run["cost1"]) <= 1e-6 * run["cost1"]
+    assert np.max(np.abs(np.array(dev["x1"]) - np.array(run["x1"]))) <= 1e-6 * max(1.0, np.max(np.abs(run["x1"])))
+    assert len(dev["cost_curve"]) == 1          # the scene's own costFunc call after the optimisation, nothing per evaluation
+    assert np.array_equal(np.array(dev["x0"]), np.array(run["x0"]))
