@@ -133,7 +133,7 @@ esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict
   }
 }
 
-// The same for columns of up to 256 voxels (NCH <= 4 chunks of 64): the ballots stay in scalar registers, what the
+// The same for columns of up to 512 voxels (NCH <= 8 chunks of 64): the ballots stay in scalar registers, what the
 // other chunks contribute to a chunk (their highest occupied voxel below it, their lowest above it) is scalar
 // arithmetic done once per column, and a lane only searches its own chunk's mask (21 -> 18 us at 200^3).  What is
 // left is instruction issue — 160 VALU + 81 SALU per column, 39 columns per SIMD — not latency: four columns per
@@ -678,6 +678,10 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
     case 2: hipLaunchKernelGGL(esdf_z_small_kernel<2>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
     case 3: hipLaunchKernelGGL(esdf_z_small_kernel<3>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
     case 4: hipLaunchKernelGGL(esdf_z_small_kernel<4>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
+    case 5: hipLaunchKernelGGL(esdf_z_small_kernel<5>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
+    case 6: hipLaunchKernelGGL(esdf_z_small_kernel<6>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
+    case 7: hipLaunchKernelGGL(esdf_z_small_kernel<7>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
+    case 8: hipLaunchKernelGGL(esdf_z_small_kernel<8>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany); break;
     default: hipLaunchKernelGGL(esdf_z_kernel, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany);
   }
   hipError_t e = hipGetLastError();

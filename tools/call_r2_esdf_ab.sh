@@ -18,8 +18,8 @@ for r in csv.DictReader(open(f)):
     if any(k in n for k in ("esdf_x", "esdf_y", "esdf_z", "esdf_rows")):
         name = n.split("(anonymous namespace)::")[1].split("(")[0]
         lo, hi = float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3
-        if "esdf_z_small" in n: tot[0] += lo; print(f"    {name:28s} 200^3 {lo:7.1f} us"); continue
-        if "esdf_z_kernel" in n: tot[1] += hi; print(f"    {name:28s} 400^3 {hi:7.1f} us"); continue
+        if "esdf_z_small_kernel<4>" in n: tot[0] += lo; print(f"    {name:28s} 200^3 {lo:7.1f} us"); continue
+        if "esdf_z" in n: tot[1] += hi; print(f"    {name:28s} 400^3 {hi:7.1f} us"); continue
         tot[0] += lo; tot[1] += hi
         print(f"    {name:28s} 200^3 {lo:7.1f} us   400^3 {hi:7.1f} us")
 print(f"    build total: 200^3 {tot[0]:.1f} us, 400^3 {tot[1]:.1f} us")
