@@ -46,6 +46,8 @@ def test_esdf_bit_exact(scene):
     ((260, 260, 8), "corner"),       # in-plane distances past 255 voxels next to small ones
     ((4, 2056, 8), "random"),        # ny past the y sweep's in-LDS candidate list: esdf_rows_kernel's lists
     ((70, 130, 68), "random"),       # two 64-voxel chunks per column, several ballots per slab's column flags
+    ((6, 10, 320), "random"),        # five chunks per column: the scalar-mask z sweep's upper variants
+    ((4, 6, 520), "random"),         # columns past 512 voxels: the LDS-mask z sweep
 ])
 def test_esdf_grid_shapes_bit_exact(gtop, grid, kind):
     """The exact EDT on grid shapes that pick each sweep variant, against scipy's exact transform."""
