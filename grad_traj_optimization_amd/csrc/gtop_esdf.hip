@@ -469,7 +469,7 @@ __device__ __forceinline__ void esdf_stamp(unsigned long long t0, int steps) {
 // that run at the same time (dealt linearly, every XCD walked every slab: 1.44 ms -> 0.96 ms at 400^3 with this
 // order).  grid = 8 * ceil(n/kXB) * bpp workgroups, bpp = workgroups per XCD and slab block, nl = lanes per slab
 // block.  Returns false for a lane without work.
-template <int BLOCK = 256>
+template <int BLOCK = 256, bool SHADOW = false>
 __device__ __forceinline__ bool esdf_x_lane(const int nl, int *fl, int *q0) {
 #ifdef GTOP_ESDF_X_PARTS   // round 2's first form: XCD c owns the c-th eighth of the plane (one contiguous part)
   const int part = (nl + 7) >> 3, bpp = (part + BLOCK - 1) / BLOCK;
@@ -487,6 +487,12 @@ __device__ __forceinline__ bool esdf_x_lane(const int nl, int *fl, int *q0) {
   const int li = (j % bpp) * BLOCK + (int)threadIdx.x;
   *q0 = (j / bpp) * kXB;
   *fl = (((li >> 6) << 3) + xcd) * 64 + (li & 63);
+  if (SHADOW) {   // a wavefront with any work keeps all its lanes: those past the end shadow the last lane with work
+    const int wave_first = *fl - (li & 63);
+    if ((li >> 6) >= cpx || wave_first >= nl) return false;
+    if (*fl >= nl) *fl = nl - 1;
+    return true;
+  }
   return (li >> 6) < cpx && *fl < nl;
 #endif
 }
@@ -537,7 +543,9 @@ esdf_x16_kernel(const GtopGrid g, const uint16_t *__restrict__ f16, const int *_
 #ifdef GTOP_ESDF_STAMPS
   const unsigned long long t0 = wall_clock64();
 #endif
-  if (!esdf_x_lane<kX16Block>(nyz >> 3, &fl, &q0)) return;
+  if (!esdf_x_lane<kX16Block, true>(nyz >> 3, &fl, &q0)) return;   // (whole wavefronts only: see the epilogue)
+  // first voxel of the wavefront's chunk of the plane: lane 0 is never a shadow
+  const int wave_base = __builtin_amdgcn_readfirstlane(fl) << 3;
   const int first = fl << 3;
   const int last = first + (n - 1) * nyz;
   int row[kXB];
@@ -615,19 +623,35 @@ esdf_x16_kernel(const GtopGrid g, const uint16_t *__restrict__ f16, const int *_
 #endif
   // every value is below 0xFFFF here: res*sqrt(.) <= 256*res, below the 10000 of sdf_map.cpp:355-361 for any
   // resolution under 39 m — the min with 10000 is kept for the letter of it
+  // A lane owns 8 consecutive voxels = 64 bytes of a row: stored from there, one store instruction would touch 64
+  // lines a quarter each.  The packed results are transposed through LDS first (lane s writes its 4 words at
+  // 4s .. 4s+3; lane l then reads word 64k + l, k = 0 .. 3: the voxel pair 128k + 2l of the wavefront's 512), so
+  // that every store instruction writes 1 KB of whole lines (the vector-memory path was 79 % busy at 400^3, nearly
+  // half of its requests these partial lines).
+  __shared__ unsigned int s_tr[kX16Block / 64][256];
+  const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
 #pragma unroll
   for (int e = 0; e < kXB; ++e) {
     if (q0 + e >= n) break;
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<uint4 *>(&s_tr[wv][4 * ln]) = *reinterpret_cast<const uint4 *>(&best[e]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int rowbase = wave_base + min(q0 + e, n - 1) * nyz;   // first voxel of the wavefront's 512 in this row
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int nn[2] = {(int)best[e].p[p].x, (int)best[e].p[p].y};
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const double r = g.res * sqrt((double)nn[h]);
-        const double dv = r < 10000.0 ? r : 10000.0;
-        dist[row[e] + 2 * p + h] = dv;
-        if (dist32) dist32[row[e] + 2 * p + h] = (float)dv;
+    for (int k = 0; k < 4; ++k) {
+      const unsigned pk = s_tr[wv][64 * k + ln];
+      const int v = 128 * k + 2 * ln;                            // voxel pair (v, v + 1) of the wavefront's chunk
+      if (wave_base + v >= nyz) continue;                        // past the end of the plane (last chunk only)
+      const int nn[2] = {(int)(pk & 0xFFFFu), (int)(pk >> 16)};
+      double2 dv;
+      {
+        const double r0 = g.res * sqrt((double)nn[0]), r1 = g.res * sqrt((double)nn[1]);
+        dv.x = r0 < 10000.0 ? r0 : 10000.0;
+        dv.y = r1 < 10000.0 ? r1 : 10000.0;
       }
+      *reinterpret_cast<double2 *>(dist + rowbase + v) = dv;
+      if (dist32) *reinterpret_cast<float2 *>(dist32 + rowbase + v) = make_float2((float)dv.x, (float)dv.y);
     }
   }
 #ifdef GTOP_ESDF_STAMPS

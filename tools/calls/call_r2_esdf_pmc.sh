@@ -7,7 +7,7 @@ rm -rf $out; mkdir -p $out
 i=0
 for ctrs in "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" ${ESDF_PMC_MORE:+"TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"}; do
   i=$((i+1))
-  timeout -k 5 150 rocprofv3 --pmc $ctrs --output-format csv -d $out/pass$i -- python3 tools/esdf_time.py 200 > $out/pass$i.log 2> $out/pass$i.err || echo "pass $i failed"
+  timeout -k 5 150 rocprofv3 --pmc $ctrs --output-format csv -d $out/pass$i -- python3 tools/esdf_time.py ${ESDF_GRID:-200} > $out/pass$i.log 2> $out/pass$i.err || echo "pass $i failed"
   echo "pass $i done: $ctrs"
 done
 python3 - <<'PY'
