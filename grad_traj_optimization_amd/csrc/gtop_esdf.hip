@@ -163,6 +163,14 @@ esdf_z_small_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__re
       lo[k] = mk[k] ? k * 64 + (__ffsll((long long)mk[k]) - 1) : kFar;
     }
     if (lane == 0) colany[col] = any != 0ull;   // the column holds an obstacle: finite for the y sweep
+    if (any == 0ull) {   // (wave-uniform) most columns of a map are empty: nothing to search
+#pragma unroll
+      for (int ko = 0; ko < NCH; ++ko) {
+        const int z = ko * 64 + lane;
+        if (z < nz) out[col * nz + z] = kInf;
+      }
+      continue;
+    }
 #pragma unroll
     for (int ko = 0; ko < NCH; ++ko) {
       int below = -kFar, above = kFar;   // nearest occupied voxel in the chunks under / over this one
