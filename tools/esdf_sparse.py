@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Diagnostic: the ESDF build on sparse maps (a few obstacles in a large empty map — the reference's own scenes)
+next to the bench's 2 % map and a reference-sized 200 x 200 x 25 grid, so that
+`rocprofv3 --kernel-trace -- python3 tools/esdf_sparse.py` lists the sweeps per map (four builds each)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
