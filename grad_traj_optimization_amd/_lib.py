@@ -91,6 +91,7 @@ def load_library():
         "gtop_set_sdf_device": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double]),
         "gtop_init_sdf_map": (C.c_int, [vp, dp, dp, C.c_double]),
         "gtop_update_sdf_map": (C.c_int, [vp, dp, C.c_int]),
+        "gtop_update_sdf_map_device": (C.c_int, [vp, vp, C.c_int, vp]),
         "gtop_get_sdf": (C.c_int, [vp, dp, ip]),
         "gtop_set_problem": (C.c_int, [vp, C.c_int, C.c_int, dp, C.c_int, dp]),
         "gtop_eval_batch": (C.c_int, [vp, C.c_int, dp, dp, dp]),
@@ -211,6 +212,15 @@ class GtopContext:
     def update_sdf_map(self, pts):
         pts = _f64(pts).reshape(-1, 3)
         self._chk(self._L.gtop_update_sdf_map(self._h, _p(pts), pts.shape[0]))
+
+    def update_sdf_map_device(self, pts, stream=None):
+        """pts: (N, 3) float64 CUDA tensor; asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        assert pts.is_cuda and pts.dtype == torch.float64 and pts.dim() == 2 and pts.shape[1] == 3
+        pts = pts.contiguous()   # (a tensor made from np.argwhere's transposed view is column-major)
+        st = stream if stream is not None else torch.cuda.current_stream()
+        self._chk(self._L.gtop_update_sdf_map_device(self._h, C.c_void_p(pts.data_ptr()), pts.shape[0],
+                                                     C.c_void_p(st.cuda_stream)))
 
     def get_sdf(self):
         g = (C.c_int * 3)()

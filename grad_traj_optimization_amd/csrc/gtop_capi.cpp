@@ -356,12 +356,8 @@ int gtop_init_sdf_map(gtop_ctx *c, const double map_size[3], const double origin
   return GTOP_OK;
 }
 
-int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
-  if (!c) return GTOP_ERR_INVALID;
-  if (npts < 0 || (npts > 0 && !pts)) return fail(c, GTOP_ERR_INVALID, "bad obstacle list");
-  if (!c->have_grid || !c->own64 || !c->occ)
-    return fail(c, GTOP_ERR_STATE, "updateSDFMap: call gtop_init_sdf_map first");
-  HIPCHK(c, hipSetDevice(c->device));
+// the build proper: obstacle points already in HBM, launches on `s`, no synchronisation
+static int update_sdf_map_on_stream(gtop_ctx *c, const double *d_pts, int npts, hipStream_t s) {
   const GtopGrid &g = c->grid;
   const size_t nvox = (size_t)g.nx * g.ny * g.nz;
   int rc;
@@ -372,18 +368,38 @@ int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
   if ((rc = ensure(c, &c->rows, &c->cap_rows, gtop_esdf_rows_ints(g)))) return rc;
   if (!gtop_esdf_supported(g))
     return fail(c, GTOP_ERR_INVALID, "updateSDFMap: grid too large for the device builder (nz <= 4096, nx, ny <= 32768)");
+  // resetBuffer (sdf_map.cpp:26-53): the occupancy; the distances need no reset of their own, the x sweep
+  // writes every voxel (10000 where the line holds no obstacle, as the reset would have left it)
+  HIPCHK(c, gtop_launch_esdf_reset(c->occ, nullptr, nvox, s));
+  HIPCHK(c, gtop_launch_esdf_mark(g, d_pts, npts, c->occ, s));         // setOccupancy
+  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, nullptr, s));   // updateESDF3d
+  c->sdf32_stale = true;   // converted by the first fp32 evaluation that needs it
+  return GTOP_OK;
+}
+
+int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (npts < 0 || (npts > 0 && !pts)) return fail(c, GTOP_ERR_INVALID, "bad obstacle list");
+  if (!c->have_grid || !c->own64 || !c->occ)
+    return fail(c, GTOP_ERR_STATE, "updateSDFMap: call gtop_init_sdf_map first");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
   if (npts > 0) {
     if ((rc = ensure(c, &c->d_pts, &c->pts_cap, (size_t)npts * 3))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, (size_t)npts * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
-  // resetBuffer (sdf_map.cpp:26-53): the occupancy; the distances need no reset of their own, the x sweep
-  // writes every voxel (10000 where the line holds no obstacle, as the reset would have left it)
-  HIPCHK(c, gtop_launch_esdf_reset(c->occ, nullptr, nvox, c->stream));
-  HIPCHK(c, gtop_launch_esdf_mark(g, c->d_pts, npts, c->occ, c->stream));         // setOccupancy
-  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, nullptr, c->stream));   // updateESDF3d
-  c->sdf32_stale = true;   // converted by the first fp32 evaluation that needs it
+  if ((rc = update_sdf_map_on_stream(c, c->d_pts, npts, c->stream))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
+}
+
+int gtop_update_sdf_map_device(gtop_ctx *c, const void *d_pts, int npts, void *hip_stream) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (npts < 0 || (npts > 0 && !d_pts)) return fail(c, GTOP_ERR_INVALID, "bad obstacle list");
+  if (!c->have_grid || !c->own64 || !c->occ)
+    return fail(c, GTOP_ERR_STATE, "updateSDFMap: call gtop_init_sdf_map first");
+  HIPCHK(c, hipSetDevice(c->device));
+  return update_sdf_map_on_stream(c, static_cast<const double *>(d_pts), npts, static_cast<hipStream_t>(hip_stream));
 }
 
 int gtop_get_sdf(gtop_ctx *c, double *dist_host, int grid_out[3]) {

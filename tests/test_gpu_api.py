@@ -281,6 +281,25 @@ def test_update_sdf_map_is_repeatable_and_resets(scene, oracle_mod):
     assert np.all(ctx.get_sdf() == 10000.0)
 
 
+def test_update_sdf_map_from_device_points(scene, gtop):
+    """gtop_update_sdf_map_device: obstacle points already in HBM, asynchronous on the caller's stream — the same
+    field, bit for bit, as the host-buffer form; an empty list resets it."""
+    import torch
+    mp, ctx0, sdf = scene
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    pts = torch.tensor(mp.obstacle_points(), device="cuda:0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())        # the upload of `pts` ran on the current stream
+    with torch.cuda.stream(side):
+        ctx.update_sdf_map_device(pts, side)
+    side.synchronize()
+    assert np.array_equal(ctx.get_sdf(), ctx0.get_sdf())
+    ctx.update_sdf_map_device(pts[:0])
+    torch.cuda.synchronize()
+    assert np.all(ctx.get_sdf() == 10000.0)
+
+
 # ---- BASELINE.json full sizes: size-independent properties (the oracle is too slow here) ----
 
 @pytest.fixture(scope="module")

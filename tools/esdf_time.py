@@ -25,6 +25,16 @@ for g in [int(a) for a in sys.argv[1:]] or [200, 400]:
         ctx.update_sdf_map(pts)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
+    dp = torch.tensor(pts, device="cuda:0")
+    ctx.update_sdf_map_device(dp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ctx.update_sdf_map_device(dp)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"grid {g}^3: gtop_update_sdf_map_device (points resident) {e0.elapsed_time(e1) * 100:.1f} us per build (5 kernels)", flush=True)
     d = ctx.get_sdf()
     print(f"grid {g}^3: {len(pts)} obstacle points, update_sdf_map {dt * 1e3:.3f} ms wall (host copy of the points included), "
           f"checksum {float(np.sum(d)):.6f}", flush=True)
