@@ -323,6 +323,56 @@ def test_full_size_esdf_properties(full_scene):
         assert np.max(np.abs(np.diff(d, axis=ax))) <= mp.resolution * (1 + 1e-12)
 
 
+@pytest.mark.timeout(600)
+def test_configs4_full_size_properties(gtop, oracle_mod):
+    """BASELINE.json configs[4] at full size: 8 192 trajectories of 12 segments (n = 99) over a 400^3 field of 4 %
+    occupancy.  The field: exact against scipy's EDT on a 400 x 400 x 40 slab of it (the whole would take minutes on
+    the host) and 1-Lipschitz everywhere; the batch: finite, cost >= 1e-3, bit-identical in reversed order and in
+    halves (rows are independent), 128 rows against the oracle."""
+    import torch
+    from scipy import ndimage
+    mp = problem.make_map(400, density=0.04, seed=2)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    d = ctx.get_sdf()
+    assert np.array_equal(d == 0.0, mp.occupancy == 1)
+    for ax in range(3):
+        assert np.max(np.abs(np.diff(d, axis=ax))) <= mp.resolution * (1 + 1e-12)
+    # exactness where a sub-block decides it alone: voxels whose distance is below their distance to the block's faces
+    blk = (slice(100, 300), slice(100, 300), slice(0, 60))
+    ref = mp.resolution * ndimage.distance_transform_edt(mp.occupancy[blk] == 0)
+    zz = np.arange(60)[None, None, :]
+    ii = np.arange(200)
+    face = np.minimum(np.minimum(ii, 199 - ii)[:, None, None], np.minimum(ii, 199 - ii)[None, :, None])
+    face = np.minimum(face, 59 - zz) + 1.0            # voxels to the nearest cut face (the z = 0 face is the map's own)
+    inner = ref < face * mp.resolution
+    assert inner.mean() > 0.5 and np.array_equal(d[blk][inner], ref[inner])
+    B, m = 8192, 12
+    b = problem.make_trajectories(B, m, mp, seed=3)
+    dev = torch.device("cuda:0")
+    x = torch.tensor(b.x, device=dev)
+    Df = torch.tensor(b.Df.reshape(-1, 18), device=dev)
+    T = torch.tensor(b.T, device=dev)
+    ctx.set_params()
+    c, g = ctx.eval_device(x, Df, T)
+    torch.cuda.synchronize()
+    assert torch.isfinite(c).all() and torch.isfinite(g).all() and (c >= 1e-3).all()
+    cr, gr = ctx.eval_device(x.flip(0).contiguous(), Df.flip(0).contiguous(), T.flip(0).contiguous())
+    h = B // 2
+    c1, g1 = ctx.eval_device(x[:h].contiguous(), Df[:h].contiguous(), T[:h].contiguous())
+    c2, g2 = ctx.eval_device(x[h:].contiguous(), Df[h:].contiguous(), T[h:].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(cr.flip(0), c) and torch.equal(gr.flip(0), g)
+    assert torch.equal(torch.cat([c1, c2]), c) and torch.equal(torch.cat([g1, g2]), g)   # 4 096 and 8 192: the same body
+    sdf = oracle_mod.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+    sdf.dist[:] = d.reshape(-1)
+    idx = np.random.default_rng(5).choice(B, 128, replace=False)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(b.T[idx], b.Df[idx], b.x[idx], sdf, oracle_mod.make_params(), nthreads=8)
+    rc, rg = scenes.rel_err(c[idx].cpu().numpy(), g[idx].cpu().numpy(), c_ref, g_ref)
+    assert rc <= TOL64 and rg <= TOL64, (rc, rg)
+
+
 @pytest.mark.parametrize("cfg", [(1024, 6, "f64"), (16384, 6, "f32"), (16384, 6, "f64")])
 def test_full_size_batch_properties(full_scene, oracle_mod, cfg):
     """configs[1], configs[2] of BASELINE.json: a 256-row subsample against the
