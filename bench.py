@@ -22,7 +22,7 @@ overlapped with the next bucket's kernels); --gather-grads adds the optional
 all-gather of each bucket's last gradient.
 
 Rank 0 prints ONE JSON line (contract in the task statement), extended with
-`roofline` (dominant kernel: gtop_eval_kernel, HBM-bound, algorithmic bytes
+`roofline` (dominant kernel: gtop_eval_wave_kernel, HBM-bound, algorithmic bytes
 of SURVEY.md §8d) and `cpu_baseline` (the oracle's C restatement timed on this
 box's host cores; N=1 only).
 
@@ -54,7 +54,7 @@ TOL = {"f64": 1e-5,     # BASELINE.json north_star
 
 
 def measured_traffic(key):
-    """HBM-side bytes per launch of gtop_eval_kernel for this workload, from the
+    """HBM-side bytes per launch of the evaluation kernel for this workload, from the
     rocprofv3 --pmc passes committed under profiles/ (tools/pmc_collect.sh +
     tools/pmc_summary.py; counters cannot be read from inside this process).
     {} when this workload has not been profiled."""
@@ -69,6 +69,21 @@ def algorithmic_bytes(m, elem):
     """per evaluation, e*[(9(m-1)+18+m) + (1+9(m-1))] + e*8*30*m."""
     n = 9 * (m - 1)
     return elem * ((n + 18 + m) + (1 + n)) + elem * 8 * 30 * m
+
+
+def dominant_kernel(m, B, dtype, pinned):
+    """Name of the kernel that serves this workload (the launcher's auto rule, csrc/gtop_capi.cpp launch_geometry and
+    csrc/gtop_kernels.hip launch_spl) — what the rocprofv3 CSVs under profiles/ list it as."""
+    R = "double" if dtype == "f64" else "float"
+    if pinned:
+        return "gtop_eval_wave_kernel / gtop_eval_kernel (pinned launch geometry)"
+    if m <= 6:
+        if dtype == "f32" and B >= 8192:
+            return f"gtop_eval_wave_kernel<{R}, false, 6, 2, true, 3>"       # packed pairs, two trajectories per wavefront
+        return f"gtop_eval_wave_kernel<{R}, false, 3, 1, true, {3 if B >= 3072 else 2}>"
+    if m <= 12 and B >= 4096:
+        return f"gtop_eval_wave_kernel<{R}, false, 6, 1, true, 3>"
+    return f"gtop_eval_kernel<{R}, ...>"
 
 
 def host_threads():
@@ -422,7 +437,7 @@ def main():
                                                if collective else 0,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "gtop_eval_kernel",
+                "bound": "hbm", "kernel": dominant_kernel(args.segments, hi - lo, args.dtype, bool(args.waves or args.spl)),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(wkey).get("traffic_bytes"),
