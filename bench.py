@@ -523,7 +523,8 @@ def _extra_workload(ctx, oracle, osdf, b, m, grid, name, dev, label, reps=200):
     tr = measured_traffic(f"B{B}_m{m}_g{grid}_{name}")
     entry.update({
         "us_per_launch": us, "evals_per_s": B / (us * 1e-6),
-        "roofline": {"bound": "hbm", "achieved": B * bpe / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": dominant_kernel(m, B, name, False),
+                     "achieved": B * bpe / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": B * bpe / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "traffic": tr.get("traffic_bytes"), "algorithmic_bytes_per_eval": bpe}})
     return entry
