@@ -221,6 +221,30 @@ esdf_rows_kernel(const GtopGrid g, const uint8_t *__restrict__ colany, int *__re
 // load is a 16-byte one: the same rows in a quarter of the instructions.  The four voxels share the scan's radius
 // (the widest of theirs; the extra candidates a voxel sees cannot win).  V = 1 serves grids whose nz is not a
 // multiple of 4.
+#ifdef GTOP_ESDF_STAMPS
+// tuning aid (tools/esdf_stamps.py): per wavefront of the x sweep, start / end on the 100 MHz wall clock, scan
+// steps and placement.  Not part of the product build.
+__device__ unsigned long long g_esdf_stamps[4 * 65536];
+#ifdef GTOP_ESDF_STAMP_Y
+constexpr bool getenv_stamp_y = true;
+#else
+constexpr bool getenv_stamp_y = false;
+#endif
+__device__ __forceinline__ void esdf_stamp(unsigned long long t0, int steps) {
+  const unsigned long long t1 = wall_clock64();
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w < 65536) {
+      g_esdf_stamps[4 * w + 0] = t0;
+      g_esdf_stamps[4 * w + 1] = t1;
+      g_esdf_stamps[4 * w + 2] = (unsigned long long)steps;
+      g_esdf_stamps[4 * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4 /* HW_ID, bits 15:0 */) |
+                                 ((unsigned long long)__smid() << 32);
+    }
+  }
+}
+#endif
+
 template <int V> struct IntV;
 template <> struct IntV<1> { int v[1]; };
 template <> struct __attribute__((aligned(16))) IntV<4> { int v[4]; };
@@ -246,6 +270,10 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
   // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: slab x (whose voxels only read
   // slab x) goes to XCD x mod 8, so a slab is fetched into ONE L2 instead of all eight.
   // grid = 8 * ceil(nx/8) * bps workgroups, bps = ceil(nyz/V/256).
+#ifdef GTOP_ESDF_STAMPS
+  const unsigned long long t0_stamp = wall_clock64();
+  int trips = 0;
+#endif
   const int bps = (nyz / V + 255) >> 8;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int x = xcd + 8 * (j / bps);
@@ -318,6 +346,9 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
   for (int k = k0 - 1; k >= 0; k -= U) {
     const int d0 = q - cx(k);
     if (__mul24(d0, d0) >= worst) break;   // in(v) >= 0: nothing farther can win
+#ifdef GTOP_ESDF_STAMPS
+    ++trips;
+#endif
     int v[U];
     IntV<V> f[U];
 #pragma unroll
@@ -338,6 +369,9 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
   for (int k = k0 + ((k0 < c && cx(k0) == q) ? 1 : 0); k < c; k += U) {
     const int d0 = cx(k) - q;
     if (__mul24(d0, d0) >= worst) break;
+#ifdef GTOP_ESDF_STAMPS
+    ++trips;
+#endif
     int v[U];
     IntV<V> f[U];
 #pragma unroll
@@ -365,6 +399,13 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
       *reinterpret_cast<uint2 *>(fout16 + i) = pk;
     }
   }
+#ifdef GTOP_ESDF_STAMPS
+  if (getenv_stamp_y) {
+    int tmax = trips;
+    for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+    esdf_stamp(t0_stamp, tmax);
+  }
+#endif
 }
 
 // x sweep (sdf_map.cpp:348-364): out(q) = min_v ((q-v)^2 + in(v)), scanning outward; then
@@ -547,24 +588,6 @@ __device__ __forceinline__ void esdf_x_scan_block(const GtopGrid &g, const int *
   }
 }
 
-#ifdef GTOP_ESDF_STAMPS
-// tuning aid (tools/esdf_stamps.py): per wavefront of the x sweep, start / end on the 100 MHz wall clock, scan
-// steps and placement.  Not part of the product build.
-__device__ unsigned long long g_esdf_stamps[4 * 65536];
-__device__ __forceinline__ void esdf_stamp(unsigned long long t0, int steps) {
-  const unsigned long long t1 = wall_clock64();
-  if ((threadIdx.x & 63) == 0) {
-    const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (w < 65536) {
-      g_esdf_stamps[4 * w + 0] = t0;
-      g_esdf_stamps[4 * w + 1] = t1;
-      g_esdf_stamps[4 * w + 2] = (unsigned long long)steps;
-      g_esdf_stamps[4 * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4 /* HW_ID, bits 15:0 */) |
-                                 ((unsigned long long)__smid() << 32);
-    }
-  }
-}
-#endif
 
 // XCD-aware order of the x sweep's work: a lane of the yz plane belongs to ONE XCD for every slab block, block
 // after block — the rows a lane reads are then shared, in one L2, with the lanes of the neighbouring slab blocks
@@ -612,7 +635,7 @@ esdf_x_kernel(const GtopGrid g, const int *__restrict__ fin, double *__restrict_
   if (!esdf_x_lane(g.ny * g.nz / V, &fl, &q0)) return;
   esdf_x_scan_block<V>(g, fin, dist, dist32, fl * V, q0, sr);
 #ifdef GTOP_ESDF_STAMPS
-  esdf_stamp(t0, -1);
+  if (!getenv_stamp_y) esdf_stamp(t0, -1);
 #endif
 }
 
@@ -779,7 +802,7 @@ esdf_x16_kernel(const GtopGrid g, const uint16_t *__restrict__ f16, const int *_
     }
   }
 #ifdef GTOP_ESDF_STAMPS
-  esdf_stamp(t0, steps_done);
+  if (!getenv_stamp_y) esdf_stamp(t0, steps_done);
 #endif
 }
 

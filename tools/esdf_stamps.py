@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Tuning aid: timeline of the x sweep's wavefronts (a library built with -DGTOP_ESDF_STAMPS, named by
-GTOP_HIP_LIB).  usage: GTOP_HIP_LIB=.../libgtop_st.so python3 tools/esdf_stamps.py [grid=200]"""
+GTOP_HIP_LIB) — or of the y sweep's (-DGTOP_ESDF_STAMPS -DGTOP_ESDF_STAMP_Y; "steps" are then the trips of its two
+candidate loops; set ESDF_WAVES_PER_BLOCK=4).  usage: GTOP_HIP_LIB=.../libgtop_st.so python3 tools/esdf_stamps.py [grid=200]"""
 import ctypes
 import os
 import sys
