@@ -300,3 +300,29 @@ def test_device_wall_clock_stop(scene, gtop):
     xb, cb = ctx.optimize_device(torch.tensor(b.x, device=dev), Df, T, lbt, ubt, 15)
     torch.cuda.synchronize()
     assert torch.equal(xa, xb) and torch.equal(ca, cb) and (ka == 5).all() and (na == 15).all()
+
+
+def test_whole_optimisation_replays_from_a_hip_graph(scene, gtop):
+    """The one-launch optimizer is a single kernel node: captured once into a hipGraph (after a first eager call has
+    sized the context's workspace) it replays bit-identically — the launch-bound form a planner loop would keep."""
+    import torch
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(200, 6, mp, seed=4321)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    dev = torch.device("cuda:0")
+    Df = torch.tensor(b.Df.reshape(-1, 18), device=dev)
+    T = torch.tensor(b.T, device=dev)
+    lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
+    ctx.set_params()
+    x0 = torch.tensor(b.x, device=dev)
+    x_e, c_e = ctx.optimize_device(x0.clone(), Df, T, lbt, ubt, 25)
+    torch.cuda.synchronize()
+    xg = x0.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        xr, cr = ctx.optimize_device(xg, Df, T, lbt, ubt, 25)
+    for _ in range(2):
+        xg.copy_(x0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(xr, x_e) and torch.equal(cr, c_e)
