@@ -497,3 +497,42 @@ def test_spatial_order_is_a_pure_permutation(scene, gtop):
     ctx.set_problem(bp.T, bp.Df)
     cp, gp = ctx.eval_batch(bp.x)
     assert np.array_equal(cp, c[perm]) and np.array_equal(gp, g[perm])
+
+
+def test_planning_cycle_as_one_hip_graph(gtop):
+    """A planner's cycle — new obstacle points (resident), field rebuild, batched optimisation — captured once as a
+    hipGraph of six kernels and replayed on changed inputs: the same results as the eager calls."""
+    import torch
+    mp = problem.make_map((80, 80, 40), density=0.03, seed=21)
+    dev = torch.device("cuda:0")
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.set_params()
+    pts_all = torch.tensor(np.ascontiguousarray(mp.obstacle_points()), device=dev)
+    npts = pts_all.shape[0] // 2
+    b = problem.make_trajectories(300, 6, mp, seed=22)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    Df = torch.tensor(b.Df.reshape(-1, 18), device=dev)
+    T = torch.tensor(b.T, device=dev)
+    lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
+    x0 = torch.tensor(b.x, device=dev)
+
+    def eager(pts):
+        ctx.update_sdf_map_device(pts)
+        x, c = ctx.optimize_device(x0.clone(), Df, T, lbt, ubt, 20)
+        torch.cuda.synchronize()
+        return x.clone(), c.clone()
+
+    want = [eager(pts_all[:npts].contiguous()), eager(pts_all[npts:2 * npts].contiguous())]
+    assert not torch.equal(want[0][1], want[1][1])          # the two obstacle sets give different optima
+    pts_g, x_g = pts_all[:npts].clone(), x0.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ctx.update_sdf_map_device(pts_g)
+        xr, cr = ctx.optimize_device(x_g, Df, T, lbt, ubt, 20)
+    for k in (0, 1, 0):
+        pts_g.copy_(pts_all[k * npts:(k + 1) * npts])
+        x_g.copy_(x0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(xr, want[k][0]) and torch.equal(cr, want[k][1])
