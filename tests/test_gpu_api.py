@@ -536,3 +536,23 @@ def test_planning_cycle_as_one_hip_graph(gtop):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(xr, want[k][0]) and torch.equal(cr, want[k][1])
+
+
+def test_empty_batches_are_no_ops(scene, gtop):
+    """B = 0 through the resident entries: GTOP_OK, nothing launched, nothing touched (the C-ABI's rule for empty
+    inputs; data pointers of empty tensors are NULL)."""
+    import torch
+    mp, ctx, sdf = scene
+    dev = torch.device("cuda:0")
+    for td in (torch.float64, torch.float32):
+        x = torch.empty(0, 45, dtype=td, device=dev)
+        Df = torch.empty(0, 18, dtype=td, device=dev)
+        T = torch.empty(0, 6, dtype=td, device=dev)
+        c, g = ctx.eval_device(x, Df, T)
+        assert c.shape == (0,) and g.shape == (0, 45)
+    x = torch.empty(0, 45, dtype=torch.float64, device=dev)
+    e = torch.empty(0, 45, dtype=torch.float64, device=dev)
+    xo, co = ctx.optimize_device(x, torch.empty(0, 18, dtype=torch.float64, device=dev),
+                                 torch.empty(0, 6, dtype=torch.float64, device=dev), e, e, 10)
+    torch.cuda.synchronize()
+    assert xo.shape == (0, 45) and co.shape == (0,)
