@@ -556,3 +556,29 @@ def test_empty_batches_are_no_ops(scene, gtop):
                                  torch.empty(0, 6, dtype=torch.float64, device=dev), e, e, 10)
     torch.cuda.synchronize()
     assert xo.shape == (0, 45) and co.shape == (0,)
+
+
+@pytest.mark.timeout(600)
+def test_batch_past_the_grid_limit(full_scene):
+    """1 114 112 trajectories (17 copies of a 65 536-row batch): more workgroups than the launcher's 2^20-block
+    grid, so the grid-stride body serves it.  Every copy must come back identical to the first (rows are
+    independent and must not depend on where in the batch they sit), finite, cost >= 1e-3, and the first copy
+    must agree with the same rows evaluated on their own (another body: summation order only)."""
+    import torch
+    mp, ctx = full_scene
+    base, reps = 65536, 17
+    b = problem.make_trajectories(base, 6, mp, seed=11)
+    dev = torch.device("cuda:0")
+    x1 = torch.tensor(b.x, device=dev)
+    Df1 = torch.tensor(b.Df.reshape(-1, 18), device=dev)
+    T1 = torch.tensor(b.T, device=dev)
+    ctx.set_params()
+    c1, g1 = ctx.eval_device(x1, Df1, T1)
+    c, g = ctx.eval_device(x1.repeat(reps, 1), Df1.repeat(reps, 1), T1.repeat(reps, 1))
+    torch.cuda.synchronize()
+    assert torch.isfinite(c).all() and torch.isfinite(g).all() and (c >= 1e-3).all()
+    cv, gv = c.view(reps, base), g.view(reps, base, -1)
+    for k in range(1, reps):
+        assert torch.equal(cv[k], cv[0]) and torch.equal(gv[k], gv[0])
+    assert torch.max(torch.abs(cv[0] - c1) / c1).item() <= 1e-12
+    assert torch.max(torch.abs(gv[0] - g1)).item() <= 1e-9 * torch.max(torch.abs(g1)).item()
