@@ -127,6 +127,8 @@ def load_library():
         "gtop_rendezvous_get_slot": (vp, [vp, C.c_int]),
         "gtop_cost_nlopt_shared": (C.c_double, [C.c_uint, dp, dp, vp]),
         "gtop_rendezvous_leave": (C.c_int, [vp]),
+        "gtop_rendezvous_set_timeout": (C.c_int, [vp, C.c_double]),
+        "gtop_rendezvous_abort": (C.c_int, [vp]),
         "gtop_rendezvous_stats": (C.c_int, [vp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64)]),
         "gtop_set_optimizer_fusion": (C.c_int, [vp, C.c_int]),
     }
@@ -497,7 +499,15 @@ class Rendezvous:
         return c, g
 
     def leave(self, i):
-        self._L.gtop_rendezvous_leave(self._slots[i])
+        return self._L.gtop_rendezvous_leave(self._slots[i])
+
+    def set_timeout(self, seconds):
+        """Longest a caller waits for the others; past it the rendezvous breaks for everybody (0 = for ever)."""
+        self._L.gtop_rendezvous_set_timeout(self._h, float(seconds))
+
+    def abort(self):
+        """Wake every caller; all calls return an error from now on."""
+        self._L.gtop_rendezvous_abort(self._h)
 
     def stats(self):
         n, cb, s = C.c_int64(), C.c_int64(), C.c_double()

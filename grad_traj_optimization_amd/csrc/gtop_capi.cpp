@@ -31,7 +31,13 @@ struct gtop_ctx {
   bool have_grid = false;
   double *sdf64 = nullptr;
   float *sdf32 = nullptr;
-  bool sdf32_stale = false;   // the fp32 copy is made on first use after gtop_update_sdf_map (a third of its writes)
+  // The fp32 copy of a rebuilt field.  gtop_update_sdf_map (host points, synchronous) defers it to the first fp32
+  // evaluation unless one has been seen on this context (`fp32_in_use`, sticky), because the copy is a third of the
+  // build's writes; gtop_update_sdf_map_device (asynchronous, capturable into a hipGraph) always enqueues it behind
+  // the build on the same stream, so that a REPLAY of the captured rebuild — which never passes through this host
+  // code again — leaves both precisions current.
+  bool sdf32_stale = false;
+  bool fp32_in_use = false;
   bool own64 = false, own32 = false;
   size_t sdf_cap64 = 0, sdf_cap32 = 0;   // elements, for owned buffers
 
@@ -47,6 +53,7 @@ struct gtop_ctx {
   double *pin_dev = nullptr; // its device address
   size_t cap_pin = 0;
   bool poll_completion = true;   // GTOP_POLL_COMPLETION=0: always wait through the stream (gtop_eval_batch)
+  uint64_t poll_sentinel = 0;    // preset of the polled output slots (GTOP_POLL_SENTINEL=<hex> overrides: tests)
   double *d_pts = nullptr;
   size_t cap_occ = 0, cap_tmp1 = 0, cap_tmp2 = 0, cap_rows = 0, pts_cap = 0;
 
@@ -265,6 +272,8 @@ int gtop_create(gtop_ctx **out, int device) {
   if (!c) return fail(nullptr, GTOP_ERR_INVALID, "gtop_create: out of memory");
   c->device = device;
   if (const char *pc = std::getenv("GTOP_POLL_COMPLETION")) c->poll_completion = std::atoi(pc) != 0;
+  c->poll_sentinel = kPollSentinel;
+  if (const char *ps = std::getenv("GTOP_POLL_SENTINEL")) c->poll_sentinel = std::strtoull(ps, nullptr, 16);
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
     delete c;
     return fail(nullptr, GTOP_ERR_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
@@ -357,7 +366,7 @@ int gtop_init_sdf_map(gtop_ctx *c, const double map_size[3], const double origin
 }
 
 // the build proper: obstacle points already in HBM, launches on `s`, no synchronisation
-static int update_sdf_map_on_stream(gtop_ctx *c, const double *d_pts, int npts, hipStream_t s) {
+static int update_sdf_map_on_stream(gtop_ctx *c, const double *d_pts, int npts, hipStream_t s, bool convert_now) {
   const GtopGrid &g = c->grid;
   const size_t nvox = (size_t)g.nx * g.ny * g.nz;
   int rc;
@@ -373,7 +382,12 @@ static int update_sdf_map_on_stream(gtop_ctx *c, const double *d_pts, int npts, 
   HIPCHK(c, gtop_launch_esdf_reset(c->occ, nullptr, nvox, s));
   HIPCHK(c, gtop_launch_esdf_mark(g, d_pts, npts, c->occ, s));         // setOccupancy
   HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, nullptr, s));   // updateESDF3d
-  c->sdf32_stale = true;   // converted by the first fp32 evaluation that needs it
+  if (c->sdf32 && (convert_now || c->fp32_in_use)) {
+    HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, s));   // device-side: holds for graph replays too
+    c->sdf32_stale = false;
+  } else {
+    c->sdf32_stale = true;   // converted by the first fp32 evaluation (host-synchronous caller only, see gtop_ctx)
+  }
   return GTOP_OK;
 }
 
@@ -388,7 +402,7 @@ int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
     if ((rc = ensure(c, &c->d_pts, &c->pts_cap, (size_t)npts * 3))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, (size_t)npts * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
-  if ((rc = update_sdf_map_on_stream(c, c->d_pts, npts, c->stream))) return rc;
+  if ((rc = update_sdf_map_on_stream(c, c->d_pts, npts, c->stream, /*convert_now=*/false))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 }
@@ -399,7 +413,8 @@ int gtop_update_sdf_map_device(gtop_ctx *c, const void *d_pts, int npts, void *h
   if (!c->have_grid || !c->own64 || !c->occ)
     return fail(c, GTOP_ERR_STATE, "updateSDFMap: call gtop_init_sdf_map first");
   HIPCHK(c, hipSetDevice(c->device));
-  return update_sdf_map_on_stream(c, static_cast<const double *>(d_pts), npts, static_cast<hipStream_t>(hip_stream));
+  return update_sdf_map_on_stream(c, static_cast<const double *>(d_pts), npts, static_cast<hipStream_t>(hip_stream),
+                                  /*convert_now=*/true);
 }
 
 int gtop_get_sdf(gtop_ctx *c, double *dist_host, int grid_out[3]) {
@@ -477,7 +492,7 @@ int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *g
     const bool poll = c->poll_completion && nout <= kPollDoubles;
     volatile uint64_t *out = reinterpret_cast<volatile uint64_t *>(c->pin + bn);
     if (poll)
-      for (size_t i = 0; i < nout; ++i) out[i] = kPollSentinel;
+      for (size_t i = 0; i < nout; ++i) out[i] = c->poll_sentinel;
     if ((rc = launch_eval<double>(c, c->sdf64, B, c->m, dpin, c->d_Df, c->d_T, c->t_stride, dpin + bn,
                                   dpin + bn + B, c->stream)))
       return rc;
@@ -486,8 +501,14 @@ int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *g
       const auto t0 = std::chrono::steady_clock::now();
       size_t i = 0;
       unsigned spins = 0;
+      // A slot has landed when BOTH of its 32-bit halves differ from the sentinel's: an 8-byte store that reached
+      // host memory as two dwords is then never taken half-written.  A genuine result that shares a half with the
+      // sentinel (2^-32 per half) is merely never "seen": the call falls back to the stream wait, never returns a
+      // wrong value.
+      const uint32_t kLo = (uint32_t)c->poll_sentinel, kHi = (uint32_t)(c->poll_sentinel >> 32);
       while (i < nout) {
-        if (out[i] != kPollSentinel) { ++i; continue; }
+        const uint64_t v = out[i];
+        if ((uint32_t)v != kLo && (uint32_t)(v >> 32) != kHi) { ++i; continue; }
         __builtin_ia32_pause();
         if ((++spins & 255u) == 0 &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kPollSeconds)
@@ -555,7 +576,10 @@ int gtop_eval_device(gtop_ctx *c, int dtype, int B, int m, const void *d_x, cons
     return launch_eval<double>(c, c->sdf64, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
   } else if (dtype == GTOP_F32) {
     if (!c->sdf32) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
-    if (c->sdf32_stale) {   // (gtop_update_sdf_map has synchronised: the fp64 field is complete)
+    c->fp32_in_use = true;
+    if (c->sdf32_stale) {
+      // only gtop_update_sdf_map leaves the copy stale, and it has synchronised: the fp64 field is complete whatever
+      // stream `s` is (gtop_update_sdf_map_device converts on its own stream, behind its build)
       const GtopGrid &g = c->grid;
       HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, (size_t)g.nx * g.ny * g.nz, s));
       c->sdf32_stale = false;

@@ -62,6 +62,8 @@ struct gtop_rendezvous {
   int active = 0, arrived = 0;
   std::atomic<uint32_t> generation{0};   // waiters sleep on this word (futex)
   int last_status = GTOP_OK;      // of the generation just evaluated
+  std::atomic<bool> broken{false};   // gtop_rendezvous_abort, or a waiter's timeout: every call returns HUGE_VAL from then on
+  double timeout_s = 0.0;         // longest a caller waits for the others (0 = for ever)
   int64_t launches = 0;
   double launch_seconds = 0.0;
 };
@@ -86,11 +88,23 @@ int usable_cores() {
   return n < 1 ? 1 : n;
 }
 
-void futex_wait(std::atomic<uint32_t> *w, uint32_t seen) {
-  syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+void futex_wait(std::atomic<uint32_t> *w, uint32_t seen, double seconds = 0.0) {
+  struct timespec ts;
+  if (seconds > 0.0) {
+    ts.tv_sec = (time_t)seconds;
+    ts.tv_nsec = (long)((seconds - (double)ts.tv_sec) * 1e9);
+  }
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, seen, seconds > 0.0 ? &ts : nullptr, nullptr, 0);
 }
 void futex_wake_all(std::atomic<uint32_t> *w) {
   syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0);
+}
+
+// A caller gave up (timeout) or the owner aborted: nobody may block any more
+void break_rendezvous(gtop_rendezvous *r) {
+  r->broken.store(true, std::memory_order_release);
+  r->generation.fetch_add(1, std::memory_order_release);
+  futex_wake_all(&r->generation);
 }
 
 // Every active slot has arrived and the caller was elected under the lock: all the other callers are blocked
@@ -151,7 +165,7 @@ double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *f
   gtop_rendezvous_slot *s = static_cast<gtop_rendezvous_slot *>(func_data);
   if (!s || !s->owner || !x) return HUGE_VAL;
   gtop_rendezvous *r = s->owner;
-  if (n != r->n) return HUGE_VAL;
+  if (n != r->n || r->broken.load(std::memory_order_acquire)) return HUGE_VAL;
   bool leader;
   uint32_t gen;
   {
@@ -168,8 +182,20 @@ double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *f
     run_generation(r);   // the last arriver evaluates for everybody
   } else {
     for (unsigned i = 0; i < r->spin && r->generation.load(std::memory_order_acquire) == gen; ++i) __builtin_ia32_pause();
-    while (r->generation.load(std::memory_order_acquire) == gen) futex_wait(&r->generation, gen);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (r->generation.load(std::memory_order_acquire) == gen) {
+      double left = 0.0;
+      if (r->timeout_s > 0.0) {
+        left = r->timeout_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (left <= 0.0) {   // a caller that never arrives (it exited without gtop_rendezvous_leave): give up, for everybody
+          break_rendezvous(r);
+          break;
+        }
+      }
+      futex_wait(&r->generation, gen, left);
+    }
   }
+  if (r->broken.load(std::memory_order_acquire)) return HUGE_VAL;
   // results of this generation stay put until every active caller — this one included — has arrived again
   if (r->last_status != GTOP_OK) return HUGE_VAL;
   const double c = r->cost[s->index];
@@ -186,11 +212,26 @@ int gtop_rendezvous_leave(gtop_rendezvous_slot *s) {
   {
     std::lock_guard<std::mutex> lk(r->mu);
     if (!s->active) return GTOP_OK;
+    // the slot's own caller is blocked inside gtop_cost_nlopt_shared right now (a leave from another thread): taking
+    // it out here would leave `arrived` counting a caller that is gone, and the others waiting for ever
+    if (s->waiting) return GTOP_ERR_STATE;
     s->active = false;          // its row keeps its last x: evaluated along, never read
     r->active--;
     leader = r->active > 0 && r->arrived == r->active;   // the others were only waiting for this one
   }
   if (leader) run_generation(r);
+  return GTOP_OK;
+}
+
+int gtop_rendezvous_set_timeout(gtop_rendezvous *r, double seconds) {
+  if (!r || !(seconds >= 0.0)) return GTOP_ERR_INVALID;
+  r->timeout_s = seconds;
+  return GTOP_OK;
+}
+
+int gtop_rendezvous_abort(gtop_rendezvous *r) {
+  if (!r) return GTOP_ERR_INVALID;
+  break_rendezvous(r);
   return GTOP_OK;
 }
 

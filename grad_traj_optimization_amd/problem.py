@@ -75,9 +75,11 @@ def segment_times(waypoints, mean_v=1.8, init_time=0.3):
     return T
 
 
-def initial_derivatives(waypoints, start_vel=None, start_acc=None):
+def initial_derivatives(waypoints, start_vel=None, start_acc=None, end_vel=None, end_acc=None):
     """Straight-line initialisation (src/qp_generator.cpp:199-221, :407-451):
-    Df (B,3,6) = [p_start, v_start, a_start, p_end, 0, 0] per axis;
+    Df (B,3,6) = [p_start, v_start, a_start, p_end, v_end, a_end] per axis
+    (the reference's getInitialD leaves v_end = a_end = 0, :418-431; the C-ABI
+    takes any row, include/gtop.h);
     Dp (B,3,3m-3): interior waypoint positions, zero velocity/acceleration."""
     wp = np.asarray(waypoints, dtype=np.float64)
     B, npts, _ = wp.shape
@@ -89,6 +91,10 @@ def initial_derivatives(waypoints, start_vel=None, start_acc=None):
         Df[:, :, 1] = start_vel
     if start_acc is not None:
         Df[:, :, 2] = start_acc
+    if end_vel is not None:
+        Df[:, :, 4] = end_vel
+    if end_acc is not None:
+        Df[:, :, 5] = end_acc
     Dp = np.zeros((B, 3, 3 * m - 3))
     Dp[:, :, 0::3] = np.transpose(wp[:, 1:m, :], (0, 2, 1))
     return Df, Dp
@@ -104,9 +110,13 @@ class Batch:
 
 
 def make_trajectories(B, m, mapspec, seed=1, step_len=(1.0, 2.0), margin=1.0, noise=0.05,
-                      mean_v=1.8, init_time=0.3):
+                      mean_v=1.8, init_time=0.3, boundary=None, boundary_scale=(1.0, 1.5)):
     """Random-walk waypoints kept `margin` metres inside the map; x is the
-    straight-line Dp plus N(0, noise^2) so velocities are non-zero."""
+    straight-line Dp plus N(0, noise^2) so velocities are non-zero.
+    boundary="random": the fixed derivatives Df carry non-zero velocity and
+    acceleration at BOTH ends, N(0, boundary_scale^2) m/s and m/s^2 — the rows a
+    kinodynamic front end hands over (setKinoPath, src/grad_traj_optimizer.cpp:35-65;
+    a replanning start state, src/qp_generator.cpp:425-431)."""
     rng = np.random.default_rng(seed)
     lo = mapspec.origin + margin
     hi = mapspec.origin + mapspec.map_size - margin
@@ -123,6 +133,12 @@ def make_trajectories(B, m, mapspec, seed=1, step_len=(1.0, 2.0), margin=1.0, no
     T = segment_times(wp, mean_v, init_time)
     Df, Dp = initial_derivatives(wp)
     x = Dp.reshape(B, -1) + rng.normal(0.0, noise, size=(B, 9 * (m - 1)))
+    if boundary == "random":        # (drawn after x: the waypoints and x of a seed do not change with the flag)
+        sv, sa = boundary_scale
+        Df, _ = initial_derivatives(wp, rng.normal(0.0, sv, (B, 3)), rng.normal(0.0, sa, (B, 3)),
+                                    rng.normal(0.0, sv, (B, 3)), rng.normal(0.0, sa, (B, 3)))
+    elif boundary is not None:
+        raise ValueError("boundary must be None or 'random'")
     return Batch(wp, T, Df, x, m)
 
 

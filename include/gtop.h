@@ -180,7 +180,13 @@ double gtop_cost_nlopt(unsigned n, const double *x, double *grad, void *ctx);
  * every slot that has not left has arrived; the last arriver runs the batch;
  * each caller gets the cost and gradient of its own row — bit for bit what
  * gtop_eval_batch gives that row.  A caller MUST call gtop_rendezvous_leave
- * when its optimizer returns, or the others wait for it forever.  Returns
+ * when its optimizer returns, or the others wait for it: for ever by default,
+ * or — after gtop_rendezvous_set_timeout(r, seconds) — until one of them has
+ * waited that long, which breaks the rendezvous for everybody (every call,
+ * pending or later, returns HUGE_VAL).  gtop_rendezvous_abort does the same at
+ * once, from any thread (an error path that cannot make every caller leave).
+ * gtop_rendezvous_leave on a slot whose caller is inside the call right now
+ * (i.e. from another thread) is refused with GTOP_ERR_STATE.  Returns
  * HUGE_VAL on misuse (wrong n, a slot that has left) or when the evaluation
  * failed (gtop_last_error(ctx)).  The context must not be used by anything
  * else while callers are inside. */
@@ -191,6 +197,8 @@ int gtop_rendezvous_destroy(gtop_rendezvous *r);
 gtop_rendezvous_slot *gtop_rendezvous_get_slot(gtop_rendezvous *r, int i);
 double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *slot);
 int gtop_rendezvous_leave(gtop_rendezvous_slot *slot);
+int gtop_rendezvous_set_timeout(gtop_rendezvous *r, double seconds);   /* 0 = wait for ever (default) */
+int gtop_rendezvous_abort(gtop_rendezvous *r);
 /* launches so far, seconds spent inside them, callbacks served (all slots) */
 int gtop_rendezvous_stats(gtop_rendezvous *r, int64_t *launches, double *launch_seconds,
                           int64_t *callbacks);

@@ -95,6 +95,13 @@ def case_small_maps():
     add("m6_click", b.T, b.Df, b.x, dict(base, ws=20.0, wc=0.1, d0=0.7))             # click.launch, App. B
     add("m6_dyn", b.T, b.Df, b.x, dict(base, enable_dyn=1, alpha_v=2.0, alpha_a=1.5))  # the commented-out block
     add("m6_shared_T", b.T[0], b.Df, b.x, base)                                        # one time vector for the batch
+    # non-zero velocity and acceleration at both ends in Df (a kinodynamic front end's rows: setKinoPath,
+    # grad_traj_optimizer.cpp:35-65; replanning start state, qp_generator.cpp:425-431), 6 and 12 segments
+    for m in (6, 12):
+        bk = problem.make_trajectories(4, m, mp, seed=80 + m, step_len=(0.5, 1.0), margin=0.4, boundary="random")
+        add(f"m{m}_kino", bk.T, bk.Df, bk.x, base)
+    bk = problem.make_trajectories(4, 6, mp, seed=93, step_len=(0.5, 1.0), margin=0.4, boundary="random")
+    add("m6_kino_dyn", bk.T, bk.Df, bk.x, dict(base, enable_dyn=1, alpha_v=2.0, alpha_a=1.5))
     # samples leaving the map: waypoints pushed through the boundary (dist = -1, grad = 0 convention)
     b2 = problem.make_trajectories(4, 4, mp, seed=78, step_len=(0.5, 1.0), margin=0.4)
     x2 = b2.x.copy()

@@ -41,3 +41,43 @@ def rel_err(c, g, c_ref, g_ref):
     rc = np.max(np.abs(c - c_ref) / np.abs(c_ref))
     rg = np.max(np.max(np.abs(g - g_ref), axis=1) / np.max(np.abs(g_ref), axis=1))
     return float(rc), float(rg)
+
+
+def write_scene(path, map_size, origin, resolution, obstacles, waypoints, velocities=None, accelerations=None,
+                segment_times=None):
+    """The text scene file tests/cpp/scene_runner.cpp reads: one `key values...` entry per item, point lists as
+    `key N` followed by N xyz rows (17 significant digits: doubles survive the round trip).  With velocities,
+    accelerations and segment_times the runner calls setKinoPath instead of setPath."""
+    def pts(f, key, a):
+        a = np.asarray(a, dtype=np.float64).reshape(-1, 3)
+        f.write(f"{key} {a.shape[0]}\n")
+        for p in a:
+            f.write("%.17g %.17g %.17g\n" % tuple(p))
+
+    with open(path, "w") as f:
+        f.write("map_size %.17g %.17g %.17g\n" % tuple(map_size))
+        f.write("origin %.17g %.17g %.17g\n" % tuple(origin))
+        f.write("resolution %.17g\n" % resolution)
+        pts(f, "obstacles", obstacles)
+        pts(f, "waypoints", waypoints)
+        if segment_times is not None:
+            pts(f, "velocities", velocities)
+            pts(f, "accelerations", accelerations)
+            t = np.asarray(segment_times, dtype=np.float64).reshape(-1)
+            f.write(f"segment_times {t.size}\n" + " ".join("%.17g" % v for v in t) + "\n")
+    return path
+
+
+def run_scene(scene_file, max_evals, on_device=0, timeout=180):
+    """Runs the scene through the C++ shim (grad_traj_optimization_amd/gtop_scene_runner) and returns its JSON."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "grad_traj_optimization_amd", "gtop_scene_runner")
+    assert os.path.exists(exe), "build() did not produce gtop_scene_runner"
+    out = subprocess.run([exe, str(scene_file), str(max_evals), str(on_device)], capture_output=True, text=True,
+                         timeout=timeout)
+    assert out.returncode == 0, out.stderr
+    txt = out.stdout
+    return json.loads(txt[txt.index("{"):txt.rindex("}") + 1])

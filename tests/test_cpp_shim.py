@@ -1,27 +1,25 @@
-"""The C++ host shim (GradTrajOptimizer-compatible class) driven like the
-reference's opti_node executable (src/opti_node.cpp:58-106), checked against
-the oracle on the same scene."""
-import json
-import os
-import subprocess
-
+"""The C++ host shim (GradTrajOptimizer-compatible class) driven through the calls the
+reference's opti_node executable makes (src/opti_node.cpp:58-106) on that executable's scene
+(tests/scenes.py holds it as data; tests/cpp/scene_runner.cpp reads the scene file), checked
+against the oracle on the same scene."""
 import numpy as np
 import pytest
 
 from tests import scenes
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEMO = os.path.join(ROOT, "grad_traj_optimization_amd", "gtop_opti_node")
 
 
 @pytest.fixture(scope="module")
-def run():
-    assert os.path.exists(DEMO), "build() did not produce gtop_opti_node"
-    out = subprocess.run([DEMO, "40"], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    txt = out.stdout
-    return json.loads(txt[txt.index("{"):txt.rindex("}") + 1])
+def scene_file(tmp_path_factory):
+    f = tmp_path_factory.mktemp("scene") / "opti_node.txt"
+    return scenes.write_scene(f, scenes.OPTI_NODE_MAP_SIZE, scenes.OPTI_NODE_ORIGIN, scenes.OPTI_NODE_RES,
+                              scenes.opti_node_obstacles(), scenes.OPTI_NODE_PATH)
+
+
+@pytest.fixture(scope="module")
+def run(scene_file):
+    return scenes.run_scene(scene_file, 40)
 
 
 def test_costfunc_signature_matches_oracle(run, oracle_mod):
@@ -68,14 +66,11 @@ def test_optimizer_improves_and_bookkeeping(run):
             assert abs(end - c[s + 1, 6 * a]) <= 1e-9 * max(1.0, abs(end))
 
 
-def test_device_optimizer_option_follows_the_host_loop(run):
+def test_device_optimizer_option_follows_the_host_loop(run, scene_file):
     """Config::optimize_on_device: the same scene with the whole optimisation as one launch of the batched
     device optimizer (10 segments: the five-lanes-per-segment loop).  Same algorithm, same evaluation cap:
     the same minimum to rounding, no per-call cost curve."""
-    out = subprocess.run([DEMO, "40", "1"], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    txt = out.stdout
-    dev = json.loads(txt[txt.index("{"):txt.rindex("}") + 1])
+    dev = scenes.run_scene(scene_file, 40, on_device=1)
     assert dev["evals"] == run["evals"] == 40
     assert abs(dev["cost1"] - run["cost1"]) <= 1e-6 * run["cost1"]
     assert np.max(np.abs(np.array(dev["x1"]) - np.array(run["x1"]))) <= 1e-6 * max(1.0, np.max(np.abs(run["x1"])))

@@ -87,6 +87,32 @@ def test_small_host_batches_complete_by_polling_or_by_stream_wait(scene, gtop, m
     t0 = time.perf_counter()
     c, g = ctxs["1"].eval_batch(x)
     assert np.isnan(c[0]) and (time.perf_counter() - t0) < 1e-3   # not the poll's 2 ms timeout
+    # A slot counts as landed only when BOTH 32-bit halves differ from the preset's (a store that arrived as two
+    # dwords is never taken half-written).  Half-match cases, forced through the preset: with ws = wc = 0 the cost is
+    # exactly 1e-3 and every gradient entry exactly 1e-5 (:418, :429-431), so a preset sharing its LOW half with 1e-3
+    # (or its HIGH half with 1e-5) makes those results invisible to the poll: the call must fall back to the stream
+    # wait after the poll's timeout and still return the right values.
+    want_c, want_g = np.float64(1e-3), np.float64(1e-5)
+    lo_c = int(want_c.view(np.uint64)) & 0xFFFFFFFF
+    hi_g = int(want_g.view(np.uint64)) >> 32
+    for preset, slow in ((0x7FF8DEAD00000000 | lo_c, True), ((hi_g << 32) | 0x5EED0BAD, True),
+                         (0x7FF8DEAD5EED0BAD, False)):
+        monkeypatch.setenv("GTOP_POLL_COMPLETION", "1")
+        monkeypatch.setenv("GTOP_POLL_SENTINEL", "%x" % preset)
+        cx = gtop.GtopContext(device=0)
+        monkeypatch.delenv("GTOP_POLL_SENTINEL")
+        cx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+        cx.update_sdf_map(mp.obstacle_points())
+        cx.set_params(ws=0.0, wc=0.0)
+        cx.set_problem(b.T, b.Df)
+        cx.eval_batch(b.x)
+        dt = np.inf
+        for _ in range(3):                                       # (the fastest of three: a stalled host is not a finding)
+            t0 = time.perf_counter()
+            c, g = cx.eval_batch(b.x)
+            dt = min(dt, time.perf_counter() - t0)
+            assert c[0] == want_c and np.all(g == want_g)
+        assert (dt > 1.5e-3) == slow, (hex(preset), dt)          # the 2 ms fallback, or not
 
 
 def test_error_codes(gtop):
@@ -205,10 +231,14 @@ def test_dyn_feasibility_every_body(scene, oracle_mod, dtype, spl, B):
     mp, ctx, sdf = scene
     td = torch.float64 if dtype == "f64" else torch.float32
     tol = TOL64 if dtype == "f64" else TOL32
-    b = problem.make_trajectories(B, 6, mp, seed=300 + B)
-    # scales at which the velocity/acceleration terms are of the order of the collision term (random-walk
-    # waypoints give |a| of tens of m/s^2; with the launch file's r_a = 1.5 the term would be e^30 and an
-    # fp32 evaluation of it meaningless)
+    # Inputs on which an fp32 evaluation is meaningful in EVERY row (none is filtered after the fact): segments of at
+    # least 0.25 s (a reflected random walk now and then puts two waypoints a few centimetres apart: T ~ 0.1 s, a jerk
+    # term of 1e6 and |a| in the hundreds), and penalty scales at which the velocity/acceleration terms are of the
+    # order of the collision term (with the launch file's r_a = 1.5 the term would be e^30).
+    pool = problem.make_trajectories(B + B // 4 + 8, 6, mp, seed=300 + B)
+    keep = np.flatnonzero(pool.T.min(axis=1) >= 0.25)[:B]
+    assert keep.size == B
+    b = problem.permute(pool, keep)
     p = dict(enable_dyn=1, alpha_v=2.0, r_v=4.0, alpha_a=1.5, r_a=15.0, step=2)
     dev = torch.device("cuda:0")
     x = torch.tensor(b.x, dtype=td, device=dev)
@@ -222,13 +252,11 @@ def test_dyn_feasibility_every_body(scene, oracle_mod, dtype, spl, B):
     finally:
         ctx.set_launch_geometry(0, 0)
         ctx.set_params()
+    assert torch.isfinite(c).all() and torch.isfinite(g).all()      # every row, both precisions
     idx = np.arange(B) if B <= 600 else np.random.default_rng(5).choice(B, 300, replace=False)
     c_ref, g_ref, _ = oracle_mod.eval_batch(b.T[idx], b.Df[idx], b.x[idx], sdf, oracle_mod.make_params(**p),
                                             nthreads=8)
-    keep = c_ref < 1e6          # a handful of rows (near-coincident waypoints, |a| in the hundreds) leave fp32's range
-    assert keep.mean() > 0.9
-    rc, rg = scenes.rel_err(c[idx][keep].double().cpu().numpy(), g[idx][keep].double().cpu().numpy(),
-                            c_ref[keep], g_ref[keep])
+    rc, rg = scenes.rel_err(c[idx].double().cpu().numpy(), g[idx].double().cpu().numpy(), c_ref, g_ref)
     assert rc <= tol and rg <= tol, (rc, rg)
 
 
@@ -536,6 +564,49 @@ def test_planning_cycle_as_one_hip_graph(gtop):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(xr, want[k][0]) and torch.equal(cr, want[k][1])
+
+
+def test_fp32_field_follows_a_replayed_rebuild(gtop):
+    """The fp32 copy of the field is refreshed ON THE DEVICE by gtop_update_sdf_map_device, so a hipGraph replay of a
+    captured rebuild (which runs no host code) leaves it current: fp32 evaluations after each replay agree with fp64
+    ones on the same field, and are bit-identical to a fresh context built eagerly from the same points."""
+    import torch
+    mp = problem.make_map((80, 80, 40), density=0.03, seed=21)
+    dev = torch.device("cuda:0")
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.set_params()
+    pts_all = torch.tensor(np.ascontiguousarray(mp.obstacle_points()), device=dev)
+    npts = pts_all.shape[0] // 2
+    b = problem.make_trajectories(200, 6, mp, seed=23)
+    t64 = [torch.tensor(a, device=dev) for a in (b.x, b.Df.reshape(-1, 18), b.T)]
+    t32 = [t.float() for t in t64]
+    # an fp32 evaluation BEFORE the capture (it used to clear the host-side "stale" flag for good)
+    ctx.update_sdf_map_device(pts_all[:npts].contiguous())
+    ctx.eval_device(*t32)
+    torch.cuda.synchronize()
+    pts_g = pts_all[:npts].clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ctx.update_sdf_map_device(pts_g)
+    seen = []
+    for k in (1, 0, 1):
+        pts_g.copy_(pts_all[k * npts:(k + 1) * npts])
+        g.replay()
+        c32, g32 = ctx.eval_device(*t32)
+        c64, g64 = ctx.eval_device(*t64)
+        torch.cuda.synchronize()
+        rc, rg = scenes.rel_err(c32.double().cpu().numpy(), g32.double().cpu().numpy(), c64.cpu().numpy(),
+                                g64.cpu().numpy())
+        assert rc <= TOL32 and rg <= TOL32, (k, rc, rg)
+        fresh = gtop.GtopContext(device=0)
+        fresh.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+        fresh.update_sdf_map(pts_all[k * npts:(k + 1) * npts].cpu().numpy())
+        cf, gf = fresh.eval_device(*t32)
+        torch.cuda.synchronize()
+        assert torch.equal(cf, c32) and torch.equal(gf, g32)
+        seen.append(c32.clone())
+    assert not torch.equal(seen[0], seen[1]) and torch.equal(seen[0], seen[2])
 
 
 def test_empty_batches_are_no_ops(scene, gtop):

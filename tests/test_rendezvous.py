@@ -31,7 +31,8 @@ def test_threads_sharing_launches_equal_the_serial_runs(threads, m, evals, spl):
     assert r["callbacks"] == r["serial_callbacks"] == sum(evals - (i % 5) for i in range(threads))
     assert r["launches"] == evals                      # one launch per generation: the longest-running caller's count
     assert r["fraction_improved"] > 0.9
-    assert r["shared_us_per_callback"] < r["serial_us_per_callback"]
+    # (wall-clock figures — shared_us_per_callback against serial_us_per_callback — are reported by
+    # tools/host_api_rate.py, not asserted: with more threads than cores they depend on the box, not the code)
 
 
 def test_python_threads_and_error_paths(gtop, oracle_mod):
@@ -46,11 +47,13 @@ def test_python_threads_and_error_paths(gtop, oracle_mod):
     got = {}
 
     def worker(i):
-        for k in range(3 + i % 3):                      # unequal call counts
-            got[(i, k)] = rdv.cost(i, b.x[i] + 0.01 * k)
-        rdv.leave(i)
+        try:
+            for k in range(3 + i % 3):                  # unequal call counts
+                got[(i, k)] = rdv.cost(i, b.x[i] + 0.01 * k)
+        finally:
+            rdv.leave(i)                                # (an error in one caller must not strand the others)
 
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    th = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(8)]
     for t in th:
         t.start()
     for t in th:
@@ -68,3 +71,44 @@ def test_python_threads_and_error_paths(gtop, oracle_mod):
         rdv2.cost(0, b.x[0][:-1])                       # n != 9(m-1)
     c, _ = rdv2.cost(0, b.x[0], want_grad=False)        # a single caller never waits
     assert c == c_ref[0]
+
+
+def test_misuse_does_not_strand_the_callers(gtop):
+    """A caller that exits without leaving, and a leave from another thread on a slot that is waiting: with a timeout
+    set the others come back with an error instead of sleeping for ever; abort wakes them at once."""
+    import time
+    mp = problem.make_map((40, 40, 20), density=0.03, seed=51)
+    b = problem.make_trajectories(3, 5, mp, seed=53)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    ctx.set_problem(b.T, b.Df)
+    for how in ("timeout", "abort"):
+        rdv = gtop.Rendezvous(ctx, 3, 5)
+        if how == "timeout":
+            rdv.set_timeout(0.3)
+        out = {}
+
+        def waiter(i, rdv=rdv, out=out):
+            t0 = time.perf_counter()
+            try:
+                rdv.cost(i, b.x[i])
+                out[i] = "returned"
+            except gtop.GtopError:
+                out[i] = time.perf_counter() - t0
+
+        th = [threading.Thread(target=waiter, args=(i,), daemon=True) for i in (0, 1)]     # caller 2 never shows up
+        for t in th:
+            t.start()
+        time.sleep(0.05)
+        assert rdv.leave(0) == 4                         # GTOP_ERR_STATE: slot 0's caller is inside the call
+        if how == "abort":
+            rdv.abort()
+        for t in th:
+            t.join(timeout=30)
+            assert not t.is_alive()
+        assert all(isinstance(out[i], float) for i in (0, 1)), out
+        if how == "timeout":
+            assert min(out.values()) >= 0.25
+        with pytest.raises(gtop.GtopError):
+            rdv.cost(2, b.x[2])                          # broken for everybody, late arrivals included
