@@ -65,6 +65,31 @@ def measured_traffic(key):
         return {}
 
 
+# Instruction-issue model: a SIMD issues one wave64 instruction of this path per CYCLES_PER_INST cycles
+# whatever its kind and however many wavefronts it holds (tools/ubench/pk_rate: 4.4-5.4 measured for fp64, scalar fp32
+# and packed fp32 at 1, 2 and 4 wavefronts per SIMD; 4 is the hardware's figure for one wavefront's stream,
+# MI355X_MICROARCH.md "vector-instruction ISSUE cost"), at the 2.4 GHz maximum clock.
+CYCLES_PER_INST = 4.5
+CLOCK_GHZ = 2.4
+N_SIMD = 1024           # 256 CUs x 4
+
+
+def issue_roofline(wkey, launch_us):
+    """`roofline_issue`: time the SIMDs need merely to ISSUE the kernel's instructions — issued instructions per
+    wavefront (SQ_INSTS_* of the committed PMC summary) x wavefronts per SIMD x cycles per instruction / clock —
+    over the measured launch time.  None when the workload has no PMC summary under profiles/."""
+    t = measured_traffic(wkey)
+    ipw, waves = t.get("issued_per_wave"), t.get("waves_per_launch")
+    if not ipw or not waves:
+        return None
+    waves_per_simd = waves / N_SIMD
+    t_issue_us = ipw["total"] * max(1.0, waves_per_simd) * CYCLES_PER_INST / (CLOCK_GHZ * 1e3)
+    return {"bound": "instruction issue", "issued_per_wavefront": ipw, "wavefronts_per_launch": waves,
+            "wavefronts_per_simd": waves_per_simd, "cycles_per_instruction": CYCLES_PER_INST, "clock_ghz": CLOCK_GHZ,
+            "issue_time_us": t_issue_us, "launch_us": launch_us, "frac": t_issue_us / launch_us,
+            "source": t.get("issue_source")}
+
+
 def algorithmic_bytes(m, elem):
     """per evaluation, e*[(9(m-1)+18+m) + (1+9(m-1))] + e*8*30*m."""
     n = 9 * (m - 1)
@@ -352,42 +377,47 @@ def main():
     barrier()
     elapsed = t1 - t0
     if short:
-        kern_ms = elapsed * 1e3 / args.steps          # host clock: launch call and completion poll included
-        kern_ms_timed, launch_src = kern_ms, "host clock around the timed region"
+        kern_ms_timed = elapsed * 1e3 / args.steps    # host clock: launch call and completion poll included
+        timed_src = f"host clock around the timed region ({args.steps} launches in {nbuckets} graph launch(es))"
     else:
-        kern_ms = ev0.elapsed_time(ev1) / args.steps     # avg per launch on the launch stream (HIP events)
-        kern_ms_timed, launch_src = kern_ms, f"HIP events around the timed region ({args.steps} launches)"
-    if short:
-        # A short timed region is one or two graph launches, and its events also see the host's launch call
-        # (~10-25 us) before the first kernel starts.  The roofline is about the kernel, so its launch time is
-        # then taken from a longer replay of the same launch plan right after the timed region (HIP events on
-        # the same stream, no collective); `value` is not affected.
-        GR, reps = 50, 20
-        scratch = torch.zeros(GR, hi - lo, dtype=tdtype, device=dev)
+        kern_ms_timed = ev0.elapsed_time(ev1) / args.steps     # avg per launch on the launch stream (HIP events)
+        timed_src = f"HIP events around the timed region ({args.steps} launches)"
+    # The roofline is about the KERNEL.  A short timed region (the driver's --steps 20) is one or two graph launches
+    # whose clock also sees the host's launch call (~10-25 us), so the kernel's sustained launch time is measured by a
+    # probe: 1 000 launches of the same kernel, graph-replayed 50 at a time, HIP events on the same stream, right
+    # after the timed region (no collective).  All three figures — timed region, probe, and the rocprofv3 average of
+    # the same command committed under profiles/ — go into the line side by side; `frac` is computed from the probe
+    # and `frac_source` says so.  `value` is never affected.
+    GR, reps = 50, 20
+    scratch = torch.zeros(GR, hi - lo, dtype=tdtype, device=dev)
 
-        def run_probe():
-            for s_ in range(GR):
-                ctx.eval_device(x, Df, T, scratch[s_], pipe.grad_ring[0])
-        probe = run_probe
-        if graphs is not None:
-            try:
-                gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph, capture_error_mode="thread_local"):
-                    run_probe()
-                gph.replay()
-                probe = gph.replay
-            except Exception:
-                torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for r in range(reps):
-            probe()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        kern_ms = e0.elapsed_time(e1) / (reps * GR)
-        launch_src = (f"HIP events around {reps * GR} launches of the same kernel ({launch_mode}, {GR} per graph) "
-                      f"after the timed region (steps < 500)")
+    def run_probe():
+        for s_ in range(GR):
+            ctx.eval_device(x, Df, T, scratch[s_], pipe.grad_ring[0])
+    probe = run_probe
+    probe_mode = "eager"
+    if graphs is not None:
+        try:
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, capture_error_mode="thread_local"):
+                run_probe()
+            gph.replay()
+            probe = gph.replay
+            probe_mode = "hipgraph"
+        except Exception:
+            torch.cuda.synchronize()
+    for r in range(reps):          # warm-up: as much work as the measured part (clocks)
+        probe()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for r in range(reps):
+        probe()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    probe_ms = e0.elapsed_time(e1) / (reps * GR)
+    probe_src = (f"HIP events around {reps * GR} launches of the same kernel ({probe_mode}, {GR} per graph) right after "
+                 f"the timed region")
 
     if collective:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -409,7 +439,13 @@ def main():
         value = evals / elapsed
         wkey = f"B{Bl}_m{m}_g{args.grid}_{args.dtype}"
         bpe = algorithmic_bytes(m, elem)
-        achieved = (hi - lo) * bpe / (kern_ms * 1e-3) / 1e9    # GB/s, per launch on this rank
+        launch_bytes = (hi - lo) * bpe
+
+        def gbs(ms):
+            return launch_bytes / (ms * 1e-3) / 1e9 if ms else None
+        achieved = gbs(probe_ms)                               # GB/s, per launch on this rank
+        meas = measured_traffic(wkey)
+        rocprof_us = meas.get("rocprof_avg_us")
         is_cfg1 = (Bl, m, args.grid, args.dtype) == (1024, 6, 200, "f64")
         par = "single GPU"
         if world > 1:
@@ -440,12 +476,23 @@ def main():
                 "bound": "hbm", "kernel": dominant_kernel(args.segments, hi - lo, args.dtype, bool(args.waves or args.spl)),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(wkey).get("traffic_bytes"),
-                "traffic_source": measured_traffic(wkey).get("source"),
+                "frac_source": "probe",
+                "traffic": meas.get("traffic_bytes"),
+                "traffic_source": meas.get("source"),
                 "algorithmic_bytes_per_eval": bpe, "evals_per_launch": hi - lo,
-                "avg_launch_us": kern_ms * 1e3, "avg_launch_us_timed_region": kern_ms_timed * 1e3,
-                "launch_time_source": launch_src,
+                # the three launch times, side by side (us) and the fraction each gives
+                "avg_launch_us": probe_ms * 1e3,
+                "launch_us": {"probe": probe_ms * 1e3, "timed_region": kern_ms_timed * 1e3, "rocprof": rocprof_us},
+                "frac_by_source": {"probe": gbs(probe_ms) / HBM_PEAK_GBS,
+                                   "timed_region": gbs(kern_ms_timed) / HBM_PEAK_GBS,
+                                   "rocprof": (gbs(rocprof_us * 1e-3) / HBM_PEAK_GBS) if rocprof_us else None},
+                "launch_us_sources": {"probe": probe_src, "timed_region": timed_src,
+                                      "rocprof": meas.get("rocprof_source")},
+                "avg_launch_us_timed_region": kern_ms_timed * 1e3,
+                "launch_time_source": probe_src,
             },
+            # what really bounds the kernel: instruction issue (the 200^3 field is cache resident)
+            "roofline_issue": issue_roofline(wkey, probe_ms * 1e3),
             "parity": parity,
             "esdf_build_s": esdf_s,
         }
@@ -526,7 +573,9 @@ def _extra_workload(ctx, oracle, osdf, b, m, grid, name, dev, label, reps=200):
         "roofline": {"bound": "hbm", "kernel": dominant_kernel(m, B, name, False),
                      "achieved": B * bpe / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": B * bpe / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": tr.get("traffic_bytes"), "algorithmic_bytes_per_eval": bpe}})
+                     "traffic": tr.get("traffic_bytes"), "algorithmic_bytes_per_eval": bpe,
+                     "launch_us": {"probe": us, "rocprof": tr.get("rocprof_avg_us")}},
+        "roofline_issue": issue_roofline(f"B{B}_m{m}_g{grid}_{name}", us)})
     return entry
 
 
@@ -535,6 +584,7 @@ def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
     (each behind its own 256-row parity gate; hipGraph replays, HIP-event time
     per launch), (2) the batched optimizer driver on the bench
     batch."""
+    import numpy as np
     import torch
     from grad_traj_optimization_amd import problem
     import grad_traj_optimization_amd as gtop
@@ -592,6 +642,30 @@ def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
             "batch": int(x.shape[0]), "evals_per_trajectory": evals, "seconds": dt_s,
             "trajectories_optimized_per_s": x.shape[0] / dt_s, **other,
             "median_cost_ratio_after_vs_before": float(torch.median(cmin / c0).item())}
+        if not args.no_cpu_baseline:
+            # The same job on the host cores: per trajectory a serial CCSA-MMA around the callback, as the reference
+            # runs NLopt's LD_MMA around costFunc (grad_traj_optimizer.cpp:137-195) — csrc/mma.hpp standing in for the
+            # absent NLopt, the oracle's C restatement as the callback; same start points, bounds and 50 evaluations.
+            ns = min(128, x.shape[0])
+            Th, Dfh, xh = batch.T[:ns], batch.Df[:ns], batch.x[:ns]
+            prm = oracle.make_params()
+            xc, cc, nev, sec1 = oracle.optimize_batch(Th, Dfh, xh, lb[:ns], ub[:ns], osdf, prm, evals, nthreads=1)
+            ncore = host_threads()
+            reps_all = max(1, min(ncore, x.shape[0] // ns))          # more rows for the all-cores run, same work per row
+            na = ns * reps_all
+            _, _, _, secn = oracle.optimize_batch(batch.T[:na], batch.Df[:na], batch.x[:na], lb[:na], ub[:na], osdf, prm,
+                                                  evals, nthreads=ncore)
+            dev_min = cmin[:ns].cpu().numpy()
+            out["optimizer"]["cpu"] = {
+                "what": "serial CCSA-MMA (csrc/mma.hpp; NLopt is absent) around the oracle callback, one trajectory at "
+                        "a time — the reference's optimizeTrajectory loop; L/R setup untimed",
+                "kind": "port", "evals_per_trajectory": int(nev.max()),
+                "trajectories_optimized_per_s": ns / sec1, "cores": 1,
+                "sample": f"the first {ns} trajectories of the same batch, {sec1:.2f} s",
+                "all_cores": {"trajectories_optimized_per_s": na / secn, "cores": ncore, "trajectories": na,
+                              "seconds": secn},
+                "max_rel_diff_of_minimum_vs_device": float(np.max(np.abs(cc - dev_min) / np.abs(cc))),
+            }
     return out
 
 

@@ -1733,7 +1733,8 @@ static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &
       if (one && spl == 3) {
         wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2>;
         if (three) wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 3> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 3>;
-      } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 1) {
+      } else if (GTOP_WAVE_SPL6 && (wave_ok || (sizeof(R) == 8 && !WIDE)) && fixed_ok && spl == 6 && args.tpb == 1) {
+        // (wave_ok = false: exactly where the fused optimizer modes run their five-lanes-per-segment loop, above)
         wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 1, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 1, false, kW6>;
       } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 2) {
         wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 2, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 2, false, kW6>;

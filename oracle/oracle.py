@@ -247,6 +247,40 @@ def eval_batch(T, Df, x, sdf, params, reps=1, nthreads=1):
     return cost, grad, sec
 
 
+_opt_lib = None
+
+
+def optimize_batch(T, Df, x0, lb, ub, sdf, params, max_evals, nthreads=1):
+    """bench.py's CPU leg beside the device optimizer (oracle/cpu_optimizer.cpp): per trajectory a serial CCSA-MMA
+    (csrc/mma.hpp standing in for NLopt's LD_MMA, grad_traj_optimizer.cpp:137-195) around the oracle callback.
+    Returns (x, min_cost, nevals, seconds)."""
+    global _opt_lib
+    if _opt_lib is None:
+        lib()
+        so = os.path.join(_HERE, "_build", "libgtop_cpu_optimizer.so")
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_build/libgtop_cpu_optimizer.so"])
+        L = C.CDLL(so)
+        dp = C.POINTER(C.c_double)
+        L.oracle_optimize_batch.argtypes = [C.c_int, C.c_int, dp, C.c_int, dp, C.POINTER(OracleParams),
+                                            C.POINTER(OracleSdf), dp, dp, dp, C.c_int, dp, C.POINTER(C.c_int), C.c_int]
+        L.oracle_optimize_batch.restype = C.c_double
+        _opt_lib = L
+    x = _f64(x0).copy()
+    B, n = x.shape
+    m = n // 9 + 1
+    T = _f64(T)
+    assert T.shape == (B, m)
+    Df = _f64(Df).reshape(B, 18)
+    lb, ub = _f64(lb), _f64(ub)
+    cost = np.zeros(B)
+    nev = np.zeros(B, dtype=np.int32)
+    sec = _opt_lib.oracle_optimize_batch(B, m, _p(T), m, _p(Df), C.byref(params), C.byref(sdf.c), _p(x), _p(lb), _p(ub),
+                                         int(max_evals), _p(cost), nev.ctypes.data_as(C.POINTER(C.c_int)), int(nthreads))
+    if sec < 0:
+        raise ValueError("oracle_optimize_batch failed")
+    return x, cost, nev, sec
+
+
 def coefficients(T, Df, x, L=None):
     """getCoefficientFromDerivative: (m, 18) coefficients, ascending powers per axis."""
     T = _f64(T)
