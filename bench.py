@@ -97,18 +97,19 @@ def algorithmic_bytes(m, elem):
 
 
 def dominant_kernel(m, B, dtype, pinned):
-    """Name of the kernel that serves this workload (the launcher's auto rule, csrc/gtop_capi.cpp launch_geometry and
-    csrc/gtop_kernels.hip launch_spl) — what the rocprofv3 CSVs under profiles/ list it as."""
+    """Name of the kernel that serves this workload (the launch rule, csrc/gtop_kernels.hip gtop_eval_plan /
+    pick_geometry) — what the rocprofv3 CSVs under profiles/ list it as.  Template arguments: arithmetic type, 64-bit
+    field indices, samples per lane, trajectories per wavefront, collision term, register budget (wavefronts per SIMD),
+    optimizer state, DYN, more than 12 segments."""
     R = "double" if dtype == "f64" else "float"
     if pinned:
-        return "gtop_eval_wave_kernel / gtop_eval_kernel (pinned launch geometry)"
+        return "gtop_eval_wave_kernel (pinned samples per lane)"
+    tail = "(anonymous namespace)::GtopNoMma, false, "
     if m <= 6:
         if dtype == "f32" and B >= 8192:
-            return f"gtop_eval_wave_kernel<{R}, false, 6, 2, true, 3>"       # packed pairs, two trajectories per wavefront
-        return f"gtop_eval_wave_kernel<{R}, false, 3, 1, true, {3 if B >= 3072 else 2}>"
-    if m <= 12 and B >= 4096:
-        return f"gtop_eval_wave_kernel<{R}, false, 6, 1, true, 3>"
-    return f"gtop_eval_kernel<{R}, ...>"
+            return f"gtop_eval_wave_kernel<{R}, false, 6, 2, true, 3, {tail}false>"   # packed pairs, two trajectories per wavefront
+        return f"gtop_eval_wave_kernel<{R}, false, 3, 1, true, {3 if B >= 3072 else 2}, {tail}false>"
+    return f"gtop_eval_wave_kernel<{R}, false, 6, 1, true, 3, {tail}{'true' if m > 12 else 'false'}>"
 
 
 def host_threads():
@@ -152,8 +153,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-sort", action="store_true",
                     help="keep the generator's random batch order (default: Morton-ordered for L2 locality)")
-    ap.add_argument("--waves", type=int, default=0, help="waves per trajectory block (0 = auto)")
-    ap.add_argument("--spl", type=int, default=0, help="samples per lane (0 = auto)")
+    ap.add_argument("--waves", type=int, default=0, help="wavefronts per workgroup (0 = auto, 1: there is one)")
+    ap.add_argument("--spl", type=int, default=0, help="samples per lane (0 = auto, 3 or 6)")
     return ap.parse_args()
 
 

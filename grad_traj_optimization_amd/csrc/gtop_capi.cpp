@@ -72,12 +72,9 @@ struct gtop_ctx {
   size_t cap_mma_vec = 0, cap_mma_scal = 0, cap_mma_int = 0, cap_mma_f = 0, cap_mma_g = 0, cap_mma_lb = 0,
          cap_mma_ub = 0;
 
-  int waves = 0;   // 0 = auto
-  int spl = 0;     // samples per lane, 0 = auto
+  int spl = 0;     // samples per lane: 0 = auto, 3 or 6 (gtop_set_launch_geometry)
   int fuse_mma = 2;         // optimizer: 0 separate update launch, 1 update fused into the evaluation kernel,
                             //            2 (default) the whole loop in one launch (tuning/debug knob)
-  int auto_spl_small = 3;   // auto, mid-size batches (m = 6: one wavefront per trajectory)
-  int auto_spl_large = 6;   // auto, large batches (m = 6: two trajectories per wavefront)
 
   // bookkeeping of the callback (grad_traj_optimizer.cpp:284, :436, :439-447)
   int64_t iter_num = 0;
@@ -167,36 +164,6 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
   return GTOP_OK;
 }
 
-// Launch geometry.  spl (samples per lane, a divisor of 30) sets how many
-// segments one wavefront holds (spw = 2, 4, 6, 10, 12, 21, 32, 64 for spl =
-// 1, 2, 3, 5, 6, 10, 15, 30); a workgroup of `waves` wavefronts then owns
-// tpb = floor(waves*spw / m) whole trajectories (at least 1).
-void launch_geometry(const gtop_ctx *c, int B, int m, int *waves, int *spl, int *tpb, int auto_spl = 0,
-                     bool f32 = false) {
-  int s = c->spl;
-  // auto rule (measured).  m <= 6: one wavefront per trajectory, gtop_eval_wave_kernel, at EVERY
-  // batch size in fp64 (B = 1: 3.45 us against 4.00 for a trajectory spread over three wavefronts; 16 384: 33.8 against
-  // 38.4 for two trajectories per wavefront) and in fp32 up to 8 192, where the packed-fp32 two-trajectory kernel takes
-  // over (22.3 against 26.0 us at 16 384).  Longer trajectories: three wavefronts' worth of lanes (one sample per lane)
-  // up to 256 of them, then one wavefront pair, from 4 096 one wavefront (six samples per lane).
-  if (s == 0) {
-    if (auto_spl) s = auto_spl;
-    else if (m <= 6) s = (f32 && B >= 8192) ? c->auto_spl_large : c->auto_spl_small;
-    else if (B <= 256) s = 1;
-    else s = (B >= 4096) ? c->auto_spl_large : c->auto_spl_small;
-  }
-  const int spw = gtop_eval_segments_per_wave(s);
-  int w = c->waves > 0 ? c->waves : (spw >= m ? 1 : (m + spw - 1) / spw);
-  if (w < 1) w = 1;
-  if (w > 8) w = 8;
-  int t = (w * spw) / m;
-  if (t < 1) t = 1;
-  if (t > 16) t = 16;
-  *waves = w;
-  *spl = s;
-  *tpb = t;
-}
-
 template <typename R>
 void fill_args(const gtop_ctx *c, GtopKernelArgs<R> &a) {
   const GtopGrid &g = c->grid;
@@ -214,13 +181,17 @@ void fill_args(const gtop_ctx *c, GtopKernelArgs<R> &a) {
   a.alpha_over_r = (R)p.alpha / (R)p.r;
   a.alpha_v = (R)p.alpha_v; a.r_v = (R)p.r_v; a.v0 = (R)p.v0;
   a.alpha_a = (R)p.alpha_a; a.r_a = (R)p.r_a; a.a0 = (R)p.a0;
+  a.inv_r_v = p.r_v != 0.0 ? (R)1 / (R)p.r_v : (R)0;   // (r_v, r_a are only read with enable_dyn, which requires them non-zero)
+  a.inv_r_a = p.r_a != 0.0 ? (R)1 / (R)p.r_a : (R)0;
+  a.gv_scale = (R)p.alpha_v * a.inv_r_v;
+  a.ga_scale = (R)p.alpha_a * a.inv_r_a;
   a.step = p.step;
 }
 
 template <typename R>
 int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const void *d_Df,
                 const void *d_T, int t_stride, void *d_cost, void *d_grad, hipStream_t stream,
-                bool wave_kernel_ok = true) {
+                bool for_optimizer = false) {
   GtopKernelArgs<R> a;
   fill_args(c, a);
   a.sdf = sdf;
@@ -230,13 +201,11 @@ int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const 
   a.cost = static_cast<R *>(d_cost);
   a.grad = static_cast<R *>(d_grad);
   a.B = B; a.m = m; a.t_stride = t_stride;
-  int waves, spl, tpb;
-  launch_geometry(c, B, m, &waves, &spl, &tpb, 0, sizeof(R) == 4);
-  while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(R)) > 64 * 1024) --tpb;
-  a.tpb = tpb;
-  if (gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(R)) > 160 * 1024)
-    return fail(c, GTOP_ERR_INVALID, "m too large for one workgroup's LDS");
-  HIPCHK(c, gtop_launch_eval<R>(a, waves, spl, c->prm.enable_dyn != 0, 1 << 20, stream, wave_kernel_ok));
+  GtopEvalPlan plan;
+  if (!gtop_eval_plan(B, m, sizeof(R), c->spl, for_optimizer, &plan))
+    return fail(c, GTOP_ERR_INVALID, "this many segments cannot be served (ten lanes per segment: up to 6 segments; "
+                                     "one wavefront's LDS: 227)");
+  HIPCHK(c, gtop_launch_eval<R>(a, plan, c->prm.enable_dyn != 0, stream));
   return GTOP_OK;
 }
 
@@ -839,14 +808,13 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   st.x0_init = nullptr;
   st.out_x = st.out_minf = nullptr;
   st.out_code = st.out_nevals = nullptr;
-  int waves, spl, tpb;
-  // whole loop in one launch: the unrolled one-trajectory-per-wavefront body wins at every batch
-  // size (measured 1024 ... 16384, tools/opt_time.py) — 10 lanes per segment up to 6 segments, 5 lanes per
-  // segment up to 12; otherwise the evaluation kernel's own rule
-  launch_geometry(c, B, m, &waves, &spl, &tpb,
-                  c->fuse_mma == 2 ? ((m > 6 && m <= 12) ? c->auto_spl_large : c->auto_spl_small) : 0);
-  const bool fused = c->fuse_mma != 0 && (spl == 1 || spl == 3 || spl == 6);
-  const bool resident = fused && c->fuse_mma == 2;   // one launch runs all max_evals evaluations of every trajectory
+  // one trajectory per wavefront in every launch form; the whole loop in one launch by default (fusion mode 2)
+  GtopEvalPlan plan;
+  if (!gtop_eval_plan(B, m, sizeof(double), c->spl, /*for_optimizer=*/true, &plan))
+    return fail(c, GTOP_ERR_INVALID, "optimize: this many segments cannot be served (ten lanes per segment: up to 6; "
+                                     "one wavefront's LDS with the optimizer's state: 118)");
+  const bool fused = c->fuse_mma != 0;
+  const bool resident = c->fuse_mma == 2;   // one launch runs all max_evals evaluations of every trajectory
   st.iters = resident ? max_evals : 1;
   GtopKernelArgs<double> a;
   fill_args(c, a);
@@ -857,14 +825,11 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   a.cost = c->mma_f;
   a.grad = c->mma_g;
   a.B = B; a.m = m; a.t_stride = time_stride;
-  if (fused)
-    while (tpb > 1 && gtop_eval_smem_bytes(m, waves, tpb, spl, sizeof(double)) > 64 * 1024) --tpb;
-  a.tpb = tpb;
-  // The whole optimisation as ONE launch where the loop runs in gtop_eval_wave_kernel (m <= 6): it initialises
-  // the state from d_x itself and writes the results where they are wanted — no init kernel in front, no copies
-  // and no finish kernel behind (each a stream operation of its own: 75 -> ~25 us of fixed cost per call).
-  const bool single = resident && gtop_eval_mma_is_wave_loop(a, waves, spl, c->prm.enable_dyn != 0, 1 << 20);
-  if (single) {
+  const bool dyn = c->prm.enable_dyn != 0;
+  // The whole optimisation as ONE launch: the loop initialises the state from d_x itself and writes the results where
+  // they are wanted — no init kernel in front, no copies and no finish kernel behind (each a stream operation of its
+  // own: 75 -> ~25 us of fixed cost per call).
+  if (resident) {
     st.x0_init = static_cast<const double *>(d_x);
     // the kernel reads the start points row by row before it writes anything there, and a row is read and written
     // by the same wavefront: d_x can be the output as well
@@ -872,17 +837,17 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
     st.out_minf = static_cast<double *>(d_minf);
     st.out_code = d_code;
     st.out_nevals = d_nevals;
-    HIPCHK(c, gtop_launch_eval_mma(a, st, waves, spl, false, 1 << 20, s));
+    HIPCHK(c, gtop_launch_eval_mma(a, st, plan, dyn, s));
     return GTOP_OK;
   }
   HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
-  for (int it = 0; it < (resident ? 1 : max_evals); ++it) {
+  for (int it = 0; it < max_evals; ++it) {
     if (fused) {
       // one launch per iteration: the evaluation kernel runs the MMA update as its epilogue
-      HIPCHK(c, gtop_launch_eval_mma(a, st, waves, spl, c->prm.enable_dyn != 0, 1 << 20, s));
+      HIPCHK(c, gtop_launch_eval_mma(a, st, plan, dyn, s));
     } else {
       if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s,
-                                    /*wave_kernel_ok=*/false)))   // the body the fused modes run: same bits
+                                    /*for_optimizer=*/true)))   // the geometry the fused modes run: same bits
         return rc;
       HIPCHK(c, gtop_launch_mma_update(st, B, (int)n, c->mma_f, c->mma_g, s));
     }
@@ -1006,11 +971,12 @@ int gtop_set_optimizer_fusion(gtop_ctx *c, int fused) {
 
 int gtop_set_launch_geometry(gtop_ctx *c, int waves, int samples_per_lane) {
   if (!c) return GTOP_ERR_INVALID;
-  if (waves < 0 || waves > 8) return fail(c, GTOP_ERR_INVALID, "waves per block must be 0 (auto) .. 8");
+  // one kernel family: a workgroup is one wavefront; the lanes-per-segment choice is what is left to pin
+  if (waves != 0 && waves != 1) return fail(c, GTOP_ERR_INVALID, "waves per workgroup must be 0 (auto) or 1");
   const int s = samples_per_lane;
-  if (!(s == 0 || (s >= 1 && s <= 30 && 30 % s == 0)))
-    return fail(c, GTOP_ERR_INVALID, "samples per lane must be 0 (auto) or a divisor of 30");
-  c->waves = waves;
+  if (s != 0 && s != 3 && s != 6)
+    return fail(c, GTOP_ERR_INVALID, "samples per lane must be 0 (auto), 3 (ten lanes per segment, up to 6 segments) "
+                                     "or 6 (five lanes per segment)");
   c->spl = s;
   return GTOP_OK;
 }

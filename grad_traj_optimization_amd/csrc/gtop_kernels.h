@@ -8,7 +8,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// Kernel arguments of gtop_eval_kernel<R>, all in the arithmetic type R of the
+// Kernel arguments of gtop_eval_wave_kernel<R>, all in the arithmetic type R of the
 // launch (double for GTOP_F64, float for GTOP_F32).
 template <typename R>
 struct GtopKernelArgs {
@@ -19,7 +19,6 @@ struct GtopKernelArgs {
   R *cost;       // [B]
   R *grad;       // [B][n]
   int B, m, t_stride;
-  int tpb;       // trajectories per workgroup (>= 1)
   // shared distance field (HBM, z fastest) — SDFMap fields, sdf_map.h:13-23
   const R *sdf;
   int nx, ny, nz;
@@ -29,6 +28,7 @@ struct GtopKernelArgs {
   // parameters — grad_traj_optimizer.cpp:5-32
   R ws, wc, alpha, d0, alpha_v, r_v, v0, alpha_a, r_a, a0;
   R inv_r, alpha_over_r;   // 1/r, alpha/r  (:509, :514)
+  R inv_r_v, inv_r_a, gv_scale, ga_scale;   // 1/r_v, 1/r_a, alpha_v/r_v, alpha_a/r_a  (:517-535, the DYN bodies)
   int step;
 };
 
@@ -53,17 +53,20 @@ struct GtopMmaState {
   int *out_code, *out_nevals;
 };
 enum { GTOP_MMA_FTOL_REACHED = 3, GTOP_MMA_XTOL_REACHED = 4, GTOP_MMA_MAXEVAL_REACHED = 5, GTOP_MMA_MAXTIME_REACHED = 6 };
-// red_rows: rows of the reduction tile (0 = the full 19; the launcher passes what the kernel variant uses)
-size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem, int red_rows = 0);
-
-// spl = samples per lane (a divisor of 30); a wavefront then holds
-// gtop_eval_segments_per_wave(spl) segments.
-int gtop_eval_segments_per_wave(int spl);
-// wave_kernel_ok = false keeps the launch on gtop_eval_kernel where gtop_eval_wave_kernel would serve it (the
-// optimizer's separate-update mode: same body, hence the same bits, as its fused modes).
+// How one launch is laid out on the wavefronts: spl = samples per lane (3: ten lanes per segment, one trajectory of up
+// to 6 segments per wavefront; 6: five lanes per segment, up to 12 segments), nt = trajectories per wavefront (2 only
+// at spl 6 with up to 6 segments), is_long = more than 12 segments (the wavefront walks them 12 at a time).
+struct GtopEvalPlan {
+  int spl, nt;
+  bool is_long;
+};
+// The launch rule.  pinned_spl: 0 = auto, 3 or 6; for_optimizer: one trajectory per wavefront (the optimizer loop and
+// the evaluations of its multi-launch forms).  false: the request cannot be served (m < 2, spl 3 with more than 6
+// segments, more segments than one wavefront's LDS holds — 227, in the optimizer loop 118).
+bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimizer, GtopEvalPlan *plan);
+// dyn: enable_dyn (the kernel applies it at step 2 only, as the commented-out block would)
 template <typename R>
-hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
-                            int max_blocks, hipStream_t stream, bool wave_kernel_ok = true);
+hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &plan, bool dyn, hipStream_t stream);
 
 hipError_t gtop_launch_f64_to_f32(const double *src, float *dst, size_t nelem,
                                   hipStream_t stream);
@@ -87,12 +90,10 @@ size_t gtop_esdf_rows_ints(const GtopGrid &g);   // ints of row workspace the bu
 hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,
                                   double *dist, float *dist32, hipStream_t stream);
 
-// fused: cost/gradient at st.xcur + MMA update in one launch (fp64; spl must be 1, 3 or 6)
-// true when gtop_launch_eval_mma with these arguments runs the one-launch loop of gtop_eval_wave_kernel (which
-// honours st.x0_init / st.out_*); the other bodies need the state initialised and the results collected around them
-bool gtop_eval_mma_is_wave_loop(const GtopKernelArgs<double> &args, int waves, int spl, bool dyn, int max_blocks);
-hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
-                                bool dyn, int max_blocks, hipStream_t stream);
+// the optimizer loop: st.iters x {cost/gradient at st.xcur, CCSA-MMA update} per trajectory in one launch (fp64; a plan
+// made with for_optimizer = true); honours st.x0_init / st.out_*
+hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
+                                bool dyn, hipStream_t stream);
 hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const double *x0, hipStream_t stream);
 hipError_t gtop_launch_mma_update(const GtopMmaState &st, int B, int n, const double *fcur, const double *gcur,
                                   hipStream_t stream);

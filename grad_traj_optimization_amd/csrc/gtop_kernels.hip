@@ -13,21 +13,23 @@
 // (src/qp_generator.cpp:357-405).  A is block diagonal, so L's row-block s is
 // A_s^-1 (quintic Hermite, closed form) scattered onto the columns of
 // waypoints s and s+1, and d'Rd = sum_s c_s' Q_s c_s.  The kernel therefore
-// takes (x, Df, T) and works per segment (geometry: DESIGN.md §5.1 — a segment
-// is sampled by LPS = 30/SPL adjacent lanes with SPL samples each, a wavefront
-// holds 64/LPS segments of one or more trajectories):
-//   phase 1  one lane per (segment, axis): c_{s,k} = A_s^-1 d_{s,k}, the jerk cost
-//            c'Qc and the jerk gradient 2Qc taken to derivative space by A_s^-T
-//   phase 2  per sample: position/velocity (float round trip), trilinear field
-//            lookup with analytic gradient, exp penalty; each sample adds
-//            w1_k*[t^j] + w2_k*[j t^(j-1)] to the lane's 18-entry
-//            coefficient-space gradient; after its samples the lane applies
-//            A_s^-T (linear, commutes with the sums) and the LPS lanes of a
-//            segment are summed through a per-wavefront LDS tile
-//   phase 4  each free variable = end of segment w-1 + start of segment w,
-//            +1e-5; the scalar cost is a DPP wavefront reduction, +1e-3; with
-//            MMA = true the workgroup then runs the optimizer update and
-//            evaluates again (the whole CCSA-MMA loop in one launch).
+// takes (x, Df, T) and works per segment.  ONE kernel family serves every
+// launch, gtop_eval_wave_kernel: a wavefront owns one or two
+// whole trajectories, a segment is sampled by LPS = 30/SPL adjacent lanes with
+// SPL samples each (SPL = 3: ten lanes, up to 6 segments; SPL = 6: five lanes,
+// up to 12 segments at a time), and the evaluation is one dependent chain:
+//   * every lane of a segment forms the segment's 18 polynomial coefficients
+//     c_{s,k} = A_s^-1 d_{s,k} in registers;
+//   * per sample: position/velocity (float round trip), trilinear field lookup
+//     with analytic gradient, exp penalty; each sample adds
+//     w1_k*[t^j] + w2_k*[j t^(j-1)] to the lane's 18-entry coefficient-space
+//     gradient, which lane 0 of the segment STARTED at the jerk term ws*2Qc;
+//   * after its samples the lane applies A_s^-T (linear, commutes with the
+//     sums); the lanes write to an LDS tile, and each free variable = end of
+//     segment w-1 + start of segment w, +1e-5, is summed from it; the scalar
+//     cost is summed the same way, +1e-3;
+//   * with the optimizer state as template argument the same wavefront then
+//     runs the CCSA-MMA update and evaluates again (the whole loop, one launch).
 // All structural zeros the reference multiplies through are skipped; nothing
 // else is approximated.
 
@@ -41,47 +43,13 @@
 
 namespace {
 
-#ifndef GTOP_SAMPLE_UNROLL
-#define GTOP_SAMPLE_UNROLL 1     // unroll factor of the per-lane sample loop (tuning knob)
-#endif
-#ifndef GTOP_MAX_THREADS
-#define GTOP_MAX_THREADS 512
-#endif
-#ifndef GTOP_F64_MIN_WAVES
-#define GTOP_F64_MIN_WAVES 2
-#endif
-#ifndef GTOP_F64_MIN_WAVES_ROLLED
-#define GTOP_F64_MIN_WAVES_ROLLED 3
-#endif
-#ifndef GTOP_F32_MIN_WAVES
-#define GTOP_F32_MIN_WAVES 3
-#endif
-#ifdef GTOP_WAVES_PER_EU         // register budget: 512 / GTOP_WAVES_PER_EU VGPRs per lane
-#define GTOP_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(GTOP_WAVES_PER_EU)))
-#else
-#define GTOP_WAVES_PER_EU_ATTR
-#endif
 constexpr int kSamples = 30;     // src/grad_traj_optimizer.cpp:351
 constexpr int kRedVals = 19;     // 18 gradient entries + 1 cost per sample
-// row stride of the transpose-reduction tile: the busy lanes of a wave (LPS*SPW of 64), made odd
+// row stride of the LDS tile: the busy lanes of a wave (LPS*SPW of 64), made odd
 constexpr int red_stride(int spl) {
   const int lps = kSamples / spl, busy = lps * (64 / lps);
   return busy | 1;
 }
-#ifndef GTOP_PIN_CONSTS
-#define GTOP_PIN_CONSTS 2
-#endif
-#ifndef GTOP_PREISSUE
-#define GTOP_PREISSUE 0
-#endif
-#ifndef GTOP_RED_CHUNK
-#define GTOP_RED_CHUNK 19
-#endif
-constexpr int kRedChunkFull = GTOP_RED_CHUNK;   // values per transpose-reduction pass
-// The specialised fp64 SPL = 6 bodies (one 40-control-point or two 20-control-point trajectories per
-// wavefront) fit 128 VGPRs; reducing in two passes of 10 rows brings their LDS to 8.8 KB per workgroup,
-// and 16 workgroups (4 wavefronts per SIMD) fit a CU.
-constexpr int red_chunk(size_t elem, int spl, int tpbc) { return (elem == 8 && spl == 6 && tpbc > 0) ? 10 : kRedChunkFull; }
 
 // Diagnostic build (-DGTOP_STAMPS): s_memtime at the phase boundaries of lane 0
 // of wave 0 of the first 4096 workgroups, into a buffer of its own that nothing
@@ -145,19 +113,15 @@ template <typename R> struct Pair { R x, y; } __attribute__((packed));
 template <typename R> constexpr bool kIsF32 = false;
 template <> constexpr bool kIsF32<float> = true;
 
-template <typename R> __device__ __forceinline__ R gexp(R v);
-template <> __device__ __forceinline__ double gexp<double>(double v) { return exp(v); }
-template <> __device__ __forceinline__ float gexp<float>(float v) { return expf(v); }
-
 // exp for the per-sample penalty (src/grad_traj_optimizer.cpp:509,:514): one
 // range reduction x = k ln2 + r, |r| <= ln2/2, a degree-11 Taylor/Horner
 // polynomial (truncation 6e-15 relative) and ldexp — about a third of the
 // instructions of the library routine.  |x| beyond the fp64 exponent range
 // saturates to 0 / inf through v_cvt_i32_f64 (saturating) and v_ldexp_f64;
 // NaN propagates through p.
-// The constants live in a struct so that the unrolled small-batch bodies can pin them
-// in VGPRs (ExpConsts::pin): 24 literal dwords less to hold in SGPRs, which those bodies
-// otherwise spill to VGPR lanes and re-materialise with s_mov pairs.
+// The constants live in a struct so that the latency variant can pin them
+// in VGPRs (ExpConsts::pin): 24 literal dwords less to hold in SGPRs, which that body
+// otherwise spills to VGPR lanes and re-materialises with s_mov pairs.
 struct ExpConsts {
   double inv_ln2 = 1.4426950408889634074, ln2_hi = -6.93147180369123816490e-01, ln2_lo = -1.90821492927058770002e-10;
   double c[9] = {2.505210838544172e-08,    // 1/11!
@@ -294,20 +258,10 @@ template <typename R> struct SdfTap {
   bool out, zflat;              // outside the map; clamped at a z border (zero z-gradient)
 };
 
-// isInMap's box (sdf_map.cpp:55-69, margins included); a struct so that the unrolled
-// small-batch bodies can keep it in VGPRs instead of 12 SGPRs (see ExpConsts)
+// isInMap's box (sdf_map.cpp:55-69, margins included) and posToIndex's constants
 template <typename R> struct MapBox {
   R lo[3], hi[3];
   R org[3], half, rinv;   // origin, res/2, 1/res of posToIndex (sdf_map.cpp:71-74, :201-204)
-  __device__ __forceinline__ void pin() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(lo[i]), "+v"(hi[i]));
-  }
-  __device__ __forceinline__ void pin_index() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(org[i]));
-    asm volatile("" : "+v"(half), "+v"(rinv));
-  }
 };
 
 template <typename R, bool WIDE>
@@ -418,9 +372,6 @@ __device__ __forceinline__ R sdf_blend(const SdfTap<R> &tp, R &gx, R &gy, R &gz,
   is_out = tp.out;
   return tp.out ? (R)-1 : dist;   // the caller zeroes the gradient's weight when out (grad := 0)
 }
-
-template <typename R>
-__device__ __forceinline__ R wave_sum(R v) { return gtop_wave_sum(v); }
 
 // sum of N consecutive values as a balanced tree (depth log2 N instead of an
 // N-long dependent chain)
@@ -540,27 +491,25 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
     w2[k] = f2_ * vel[k];
     w3[k] = splat(0.0f);
   }
-  if (DYN && a.step == 2) {   // the commented-out block :383-407 (see the scalar path)
-    f2 cv = splat(0.0f), ca = splat(0.0f);
+  if constexpr (DYN) {
+    // the commented-out block :383-407 with the formulas of :517-535 (see the fp64 path of gtop_eval_wave_kernel): per
+    // axis cv = alpha_v exp((|v| - v0)/r_v), ca likewise; in the gradient cv, ca are the LAST axis's, no sign(v)
+    f2 ev[3], ea[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const f2 av = (f2){fabsf(vel[k].x), fabsf(vel[k].y)}, aa = (f2){fabsf(acc3[k].x), fabsf(acc3[k].y)};
-      const f2 xv = (av - splat(a.v0)) / splat(a.r_v), xa = (aa - splat(a.a0)) / splat(a.r_a);
-      cv = splat(a.alpha_v) * (f2){expf(xv.x), expf(xv.y)};
-      ca = splat(a.alpha_a) * (f2){expf(xa.x), expf(xa.y)};
-      csum += (cv + ca) * vn * splat(dt);
+      const f2 xv = ((f2){fabsf(vel[k].x), fabsf(vel[k].y)} - splat(a.v0)) * splat(a.inv_r_v);
+      const f2 xa = ((f2){fabsf(acc3[k].x), fabsf(acc3[k].y)} - splat(a.a0)) * splat(a.inv_r_a);
+      ev[k] = (f2){__expf(xv.x), __expf(xv.y)};
+      ea[k] = (f2){__expf(xa.x), __expf(xa.y)};
     }
+    const f2 sdt = {liveA ? dt : 0.0f, liveB ? dt : 0.0f};   // every term of the block carries dt; 0 past the loop bound
+    csum += (splat(a.alpha_v) * ((ev[0] + ev[1]) + ev[2]) + splat(a.alpha_a) * ((ea[0] + ea[1]) + ea[2])) * vn * sdt;
+    const f2 clast = (splat(a.alpha_v) * ev[2] + splat(a.alpha_a) * ea[2]) * ivn;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const f2 av = (f2){fabsf(vel[k].x), fabsf(vel[k].y)}, aa = (f2){fabsf(acc3[k].x), fabsf(acc3[k].y)};
-      const f2 xv = (av - splat(a.v0)) / splat(a.r_v), xa = (aa - splat(a.a0)) / splat(a.r_a);
-      const f2 gv = splat(a.alpha_v / a.r_v) * (f2){expf(xv.x), expf(xv.y)};
-      const f2 ga = splat(a.alpha_a / a.r_a) * (f2){expf(xa.x), expf(xa.y)};
-      w2[k] += (gv * vn + cv * (vel[k] * ivn) + ca * (vel[k] * ivn)) * splat(dt);
-      w3[k] = (ga * vn) * splat(dt);
+      w2[k] += (splat(a.gv_scale) * ev[k] * vn + clast * vel[k]) * sdt;
+      w3[k] = (splat(a.ga_scale) * ea[k] * vn) * sdt;
     }
-    if (!liveA) { csum.x = 0.0f; w2[0].x = w2[1].x = w2[2].x = 0.0f; w3[0].x = w3[1].x = w3[2].x = 0.0f; }
-    if (!liveB) { csum.y = 0.0f; w2[0].y = w2[1].y = w2[2].y = 0.0f; w3[0].y = w3[1].y = w3[2].y = 0.0f; }
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -580,513 +529,6 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
     }
   }
   acc2[18] += csum;
-}
-
-// One workgroup owns TPB consecutive trajectories (grid-stride over groups of
-// TPB), NW = blockDim/64 wavefronts.  Each polynomial segment is sampled by
-// LPS = 30/SPL adjacent lanes, SPL samples per lane (sample index =
-// lane-in-segment + j*LPS, so neighbouring lanes gather neighbouring voxels); a
-// wavefront holds SPW = 64/LPS segments.  The workgroup's segments are
-// numbered S = tl*m + s over its TPB trajectories ("virtual segments"), so the
-// few-lane phases (1, 3, 4) and the reduction serve TPB trajectories per pass.
-//   SPL = 1, NW = 3, TPB = 1 : a 20-control-point trajectory over 3 wavefronts
-//                              (small, latency-bound batches)
-//   SPL = 3, NW = 1, TPB = 1 : one wavefront per trajectory (60/64 lanes)
-//   SPL = 15, NW = 1, TPB = 5: 2 lanes per segment, 5 trajectories per wavefront
-// Register budget (waves per SIMD the compiler must leave room for).  fp64: the
-// rolled sample loops (SPL >= 5, the large-batch geometries) fit 168 VGPRs = 3
-// waves per SIMD without spilling; the unrolled small-batch bodies need ~210 and
-// the optional velocity/acceleration block (DYN) and the optimizer epilogue (MMA) more.  fp32: 3 waves; the
-// 128-VGPR budget of 4 waves spills.
-template <typename R, int SPL, bool DYN, bool MMA, int TPBC> struct MinWaves {
-  static constexpr int v = (!DYN && !MMA && SPL == 6 && TPBC > 0) ? 4
-                           : (!DYN && !MMA && (SPL == 5 || SPL == 6)) ? GTOP_F64_MIN_WAVES_ROLLED : GTOP_F64_MIN_WAVES;
-};
-template <int SPL, bool DYN, bool MMA, int TPBC> struct MinWaves<float, SPL, DYN, MMA, TPBC> {
-  static constexpr int v = DYN ? 2 : ((SPL == 6 && TPBC > 0 && !MMA) ? 4 : GTOP_F32_MIN_WAVES);
-};
-
-//
-// MMA = true (fp64 only) appends the optimizer step: `a.x` is then the trial
-// point st.xcur of the batched CCSA-MMA driver, and after cost and gradient of
-// a trajectory are known the same workgroup runs its MMA update
-// (gtop_mma_update_trajectory) and — st.iters times in all — evaluates again.
-template <typename R, bool DYN, int SPL, bool MMA, bool WIDE, int TPBC>
-__global__ void __launch_bounds__(GTOP_MAX_THREADS, (MinWaves<R, SPL, DYN, MMA, TPBC>::v)) GTOP_WAVES_PER_EU_ATTR
-gtop_eval_kernel(const GtopKernelArgs<R> a, const GtopMmaState st) {
-  constexpr int LPS = kSamples / SPL;        // lanes per segment
-  constexpr int SPW = 64 / LPS;              // segments per wavefront
-  constexpr int kRedStride = red_stride(SPL);
-  constexpr int kRedChunk = red_chunk(sizeof(R), SPL, TPBC);
-  // up to three samples per lane are unrolled outright (the small-batch geometry: one wavefront per SIMD,
-  // the scheduler interleaves the samples); longer loops stay rolled to hold 2 waves per SIMD
-  constexpr int kUnroll = (SPL <= 3 && !DYN) ? SPL : GTOP_SAMPLE_UNROLL;
-  constexpr int CH = (GTOP_PREISSUE && SPL <= 3) ? SPL : 1;   // distance-field lookups in flight per lane
-  static_assert(LPS * SPL == kSamples, "SPL must divide 30");
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  R *sm = reinterpret_cast<R *>(smem_raw);
-  const int m = a.m, ndp = 3 * m - 3, n = 3 * ndp;
-  // TPBC > 0: the launcher guarantees one wavefront per workgroup holding TPBC whole
-  // trajectories (2 <= m, TPBC m <= SPW) and a workgroup per group.  With that known at
-  // compile time the work-distribution loops of every phase collapse to straight-line code
-  // (a lone wavefront pays four cycles per instruction of any kind) and the loop-invariant
-  // lane predicates no longer overflow the SGPR file.  ONE = the single-trajectory case.
-  constexpr bool FIXED = TPBC > 0, ONE = TPBC == 1;
-  if constexpr (FIXED) __builtin_assume(m >= 2 && TPBC * m <= SPW);
-  const int TPB = FIXED ? TPBC : a.tpb, MS = TPB * m;   // trajectories / virtual segments per workgroup
-  const int tid = threadIdx.x, nthr = FIXED ? 64 : (int)blockDim.x;
-  if constexpr (FIXED) __builtin_assume(tid >= 0 && tid < 64);
-  const int lane = tid & 63, wave = FIXED ? 0 : tid >> 6, NW = FIXED ? 1 : nthr >> 6;
-  const int slot = lane / LPS, li = lane - slot * LPS;   // segment slot in this wave, lane in segment
-
-  R *Ts = sm;                // [MS]       segment_time
-  R *coef = Ts + MS;         // [MS][3][6] polynomial coefficients (:253-279)
-  R *Gs = coef + 18 * MS;    // [MS][3][6] jerk gradient, derivative space
-  R *csm = Gs + 18 * MS;     // [MS][3]    jerk cost per (segment, axis)
-  R *dts = csm + 3 * MS;     // [MS]       T_s / 30 (:351)
-  R *ccol = Ts;              // [MS]       wc * collision (+dyn) cost per segment; takes the place of T_s,
-                             //            which only the segment's own wavefront reads, before it writes this
-  R *gseg = coef;            // [MS][3][6] total gradient per segment, derivative space [p0,pT,v0,vT,a0,aT];
-                             //            written by a wavefront over ITS segments' coef after its sample loop
-  R *red = dts + MS;         // [NW][kRedChunk][kRedStride] per-wave transpose-reduction tile
-  R *myred = red + wave * (kRedChunk * kRedStride);
-
-  const R ws = (a.step == 1) ? (R)0 : a.ws;  // :412-415
-  ExpConsts expk;
-  R pen_d0 = a.d0, pen_inv_r = a.inv_r, pen_alpha = a.alpha, pen_gd = -a.alpha_over_r;   // penalty parameters (:507-515)
-  MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
-                      {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
-  if constexpr (GTOP_PIN_CONSTS && !kIsF32<R> && SPL <= 3 && !MMA && !DYN) {   // (MMA/DYN bodies have no VGPRs to spare)
-    expk.pin();
-    if (GTOP_PIN_CONSTS > 1) mapbox.pin();
-    if (GTOP_PIN_CONSTS > 2) mapbox.pin_index();
-    if (GTOP_PIN_CONSTS > 3) asm volatile("" : "+v"(pen_d0), "+v"(pen_inv_r), "+v"(pen_alpha), "+v"(pen_gd));
-  }
-  const R wc = a.wc;
-  const bool do_colli = !(gabs(wc) < (R)1e-4);  // :346
-  const unsigned long long t_launch = MMA ? wall_clock64() : 0ull;   // for the wall-clock stop of the optimizer loop
-
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blocks b
-  // and b+8 share an L2), so give XCD x the x-th contiguous eighth of the
-  // batch: with a spatially ordered batch each L2 then serves one region of
-  // the distance field.  Pure speed; any order is correct.
-  const int ngroups = (a.B + TPB - 1) / TPB;
-  const int per_xcd = (ngroups + 7) >> 3;
-  for (int vb = blockIdx.x; vb < 8 * per_xcd; vb += gridDim.x) {
-    const int grp = (vb & 7) * per_xcd + (vb >> 3);
-    if (grp >= ngroups) continue;      // block-uniform
-    const int b0 = grp * TPB;
-    // MMA: the trajectories of a group are independent of every other group, so the whole
-    // optimizer loop of the group runs here — evaluate at xcur, update, evaluate again —
-    // with st.iters evaluations per launch.  What one wavefront of the workgroup writes
-    // (xcur and the MMA state) the next pass reads after a workgroup barrier; the CU's
-    // vector L1 is shared by the workgroup, so that needs no cache maintenance.
-    const int npass = MMA ? st.iters : 1;
-    for (int pass = 0; pass < npass; ++pass) {
-    GTOP_STAMP(0);
-    GTOP_STAMP_HWID();
-    const int ntraj = ONE ? 1 : min(TPB, a.B - b0);   // trajectories this pass
-    if constexpr (MMA) {
-      // Stop rules (mma.hpp:35-39; the reference's own is set_maxtime, :144-148): a group whose trajectories have
-      // all stopped (ftol/xtol, gtop_mma_update_trajectory) leaves the loop instead of burning the remaining
-      // evaluations; past the wall-clock limit the ones still running stop where they are (after at least one
-      // evaluation).  Decided by one lane and shared through LDS: the branch must be workgroup-uniform.
-      __shared__ int s_stop;
-      if (tid == 0) {
-        int running = 0;
-        for (int tl = 0; tl < ntraj; ++tl)
-          running += __hip_atomic_load(&st.state[b0 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3;
-        int stop = running == 0;
-        if (!stop && st.max_ticks > 0 && pass > 0 && (long long)(wall_clock64() - t_launch) > st.max_ticks) {
-          for (int tl = 0; tl < ntraj; ++tl)
-            if (__hip_atomic_load(&st.state[b0 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3)
-              st.state[b0 + tl] = GTOP_MMA_MAXTIME_REACHED;
-          stop = 1;
-        }
-        s_stop = stop;
-      }
-      __syncthreads();
-      const int stop = s_stop;
-      __syncthreads();   // s_stop is rewritten by the next pass
-      if (stop) break;
-    }
-    const int nseg = ntraj * m;             // live virtual segments
-    // ---- phase 1: per (segment, axis): coefficients, jerk cost and jerk gradient ----
-    // Its 3*m*TPB lanes read their seven inputs (two waypoints' p,v,a and T_s)
-    // straight from HBM/L2 — there is no staging pass: nothing else needs x or Df.
-    for (int w = tid; w < 3 * nseg; w += nthr) {
-      const int S = w / 3, k = w - 3 * S;
-      int tl = 0, s = S;
-      if constexpr (TPBC == 2) {
-        tl = s >= m;
-        s -= tl * m;
-      } else if constexpr (!ONE) {
-        while (s >= m) { s -= m; ++tl; }
-      }
-      const R *xk = a.x + (size_t)(b0 + tl) * n + k * ndp;    // free variables of axis k (:182-187)
-      const R *df = a.Df + (size_t)(b0 + tl) * 18 + k * 6;    // [p,v,a]_start, [p,v,a]_end
-      // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
-      const R *w0 = (s == 0) ? df : xk + 3 * (s - 1);
-      const R *w1 = (s + 1 == m) ? df + 3 : xk + 3 * s;
-      const R p0 = w0[0], v0 = w0[1], a0 = w0[2];
-      const R pT = w1[0], vT = w1[1], aT = w1[2];
-      const R T = a.T[(size_t)(b0 + tl) * a.t_stride + s];
-      const R T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
-      const R iT = fast_rcp(T), iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
-      // closed-form A_s^-1 (rows of A_s: src/qp_generator.cpp:185-195)
-      const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
-      const R V = (vT - v0 - a0 * T) * T;
-      const R A = (aT - a0) * T2;
-      const R c3 = ((R)10 * P - (R)4 * V + (R)0.5 * A) * iT3;
-      const R c4 = ((R)-15 * P + (R)7 * V - A) * iT4;
-      const R c5 = ((R)6 * P - (R)3 * V + (R)0.5 * A) * iT5;
-      R *cf = coef + w * 6;
-      cf[0] = p0; cf[1] = v0; cf[2] = (R)0.5 * a0; cf[3] = c3; cf[4] = c4; cf[5] = c5;
-      // jerk Hessian Q_s (src/qp_generator.cpp:226-234): i,j in {3,4,5}
-      const R q3 = (R)36 * T * c3 + (R)72 * T2 * c4 + (R)120 * T3 * c5;
-      const R q4 = (R)72 * T2 * c3 + (R)192 * T3 * c4 + (R)360 * T4 * c5;
-      const R q5 = (R)120 * T3 * c3 + (R)360 * T4 * c4 + (R)720 * T5 * c5;
-      csm[w] = c3 * q3 + c4 * q4 + c5 * q5;   // c'Qc  == this (s,k)'s share of d'Rd (:326-327)
-      // ws * 2Qc == share of ws*(2Rfp'df + 2Rpp dp) (:330-336), taken to derivative
-      // space [p0,pT,v0,vT,a0,aT] by A_s^-T right away (its coefficient-space
-      // entries 0..2 are zero)
-      const R H3 = ws * (R)2 * q3 * iT3, H4 = ws * (R)2 * q4 * iT4, H5 = ws * (R)2 * q5 * iT5;
-      const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
-      R *g = Gs + w * 6;
-      g[0] = -ap;
-      g[1] = ap;
-      g[2] = T * ((R)-6 * H3 + (R)8 * H4 - (R)3 * H5);
-      g[3] = T * ((R)-4 * H3 + (R)7 * H4 - (R)3 * H5);
-      g[4] = T2 * ((R)-1.5 * H3 + (R)1.5 * H4 - (R)0.5 * H5);
-      g[5] = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
-      if (k == 0) {
-        Ts[S] = T;
-        dts[S] = T / (R)30.0;   // :351
-        if (!do_colli) ccol[S] = (R)0;   // (aliases Ts: only when the sample phase will not read it)
-      }
-      if constexpr (FIXED) break;   // 3 TPBC m <= 3 SPW <= 64 work items: one trip
-    }
-    __syncthreads();
-    GTOP_STAMP(1);
-    GTOP_STAMP(2);
-
-    // Sample times: the reference's `for (t = 1e-3; t < T; t += dt)` (:353)
-    // accumulates t by repeated addition.  For T >= 0.0301 all 30 samples pass the
-    // loop test whatever the rounding, and t_i = 1e-3 + i*dt differs from the
-    // accumulated value by a few ulp (1e-15 relative, far inside the 1e-5 budget;
-    // SURVEY A.4 Q8), so lanes form it with one fma.  Below that the sample COUNT
-    // depends on the accumulated value (29 at T = 0.03, fewer for tinier T), so for
-    // those segments each lane replays the addition chain.
-    // ---- phase 2: collision samples (:345-409) ----
-    if (do_colli) {
-      for (int s0 = 0; s0 < nseg; s0 += SPW * NW) {   // block-uniform trip count
-        const int S = s0 + wave * SPW + slot;
-        const bool seg_ok = (slot < SPW) & (S < nseg);
-        // idle lanes shadow a live segment (their own wavefront's first one when it has
-        // any) so that they compute on finite data; their results are never read
-        const int s_first = s0 + wave * SPW;
-        const int sc = seg_ok ? S : (s_first < nseg ? s_first : 0);
-        R acc[kRedVals];
-#pragma unroll
-        for (int v = 0; v < kRedVals; ++v) acc[v] = (R)0;
-        const R Tseg = Ts[sc];
-        const R dt = dts[sc];
-        const R wdt = wc * dt;
-        const bool tiny_T = Tseg < (R)0.0301;
-        const bool any_tiny = __ballot(tiny_T) != 0ull;   // scalar: the replay below is skipped by a uniform branch
-        int coff = sc * 18;
-        if constexpr (kIsF32<R> && (SPL % 2 == 0)) {
-          // packed fp32: samples jj and jj+1 of this lane together
-          f2 acc2[kRedVals];
-#pragma unroll
-          for (int v = 0; v < kRedVals; ++v) acc2[v] = (f2){0.0f, 0.0f};
-#pragma unroll GTOP_SAMPLE_UNROLL
-          for (int jj = 0; jj < SPL; jj += 2) {
-            asm volatile("" : "+v"(coff));
-            const float *cq = reinterpret_cast<const float *>(coef) + coff;
-            const int si = li + jj * LPS;
-            f2 t = {(float)si * (float)dt + 1e-3f, (float)(si + LPS) * (float)dt + 1e-3f};
-            if (any_tiny && tiny_T) {   // rare (the first test is wave-uniform): exact replay of `t += dt`
-              float ta = 1e-3f;
-              for (int i = 0; i < si; ++i) ta += (float)dt;
-              float tb = ta;
-              for (int i = 0; i < LPS; ++i) tb += (float)dt;
-              t = (f2){ta, tb};
-            }
-            const bool liveA = seg_ok & (t.x < (float)Tseg), liveB = seg_ok & (t.y < (float)Tseg);
-            sample_pair_f32<DYN, WIDE>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, t, liveA, liveB,
-                                 (float)wdt, (float)dt, acc2);
-          }
-#pragma unroll
-          for (int v = 0; v < kRedVals; ++v) acc[v] = (R)(acc2[v].x + acc2[v].y);
-        } else
-#pragma unroll kUnroll
-        for (int j0 = 0; j0 < SPL; j0 += CH) {
-          // Stage A, CH samples: sample time, position/velocity polynomials, distance-field
-          // index arithmetic and the corner loads.  With CH > 1 (the latency
-          // regime: one wavefront per SIMD, nothing else to hide a miss behind) all
-          // CH lookups are in flight before the first is consumed.
-          R ts[CH], vels[CH][3], accs[CH][3];
-          bool lives[CH];
-          SdfTap<R> taps[CH];
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            // the 18 coefficients are re-read from LDS for every sample (broadcast
-            // reads) instead of living in 36 VGPRs across the loop; the empty asm
-            // keeps the compiler from hoisting them back out.
-            asm volatile("" : "+v"(coff));
-            const R *cq = coef + coff;
-            const int si = li + (j0 + c) * LPS;                           // sample index 0..29
-            R t = (R)si * dt + (R)1e-3;
-            if (any_tiny) {   // wave-uniform, rare: exact replay of `t += dt`
-              if (tiny_T) {
-                t = (R)1e-3;
-                for (int i = 0; i < si; ++i) t += dt;
-              }
-            }
-            ts[c] = t;
-            lives[c] = seg_ok & (t < Tseg);   // the loop condition of :353
-            const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-            const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;   // d/dt of the powers
-            R pos[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const R *q = cq + 6 * k;
-              // :457-465 / :477-485 (sums in the reference's order), then the float round trip
-              pos[k] = round_through_float(q[0] + q[1] * t + q[2] * t2 + q[3] * t3 + q[4] * t4 + q[5] * t5);
-              vels[c][k] = round_through_float(q[1] + q[2] * d2 + q[3] * d3 + q[4] * d4 + q[5] * d5);
-              if (DYN)  // :497-502
-                accs[c][k] = round_through_float((R)2 * q[2] + (R)6 * q[3] * t + (R)12 * q[4] * t2 + (R)20 * q[5] * t3);
-            }
-            taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
-          }
-          if constexpr (CH > 1) __builtin_amdgcn_sched_barrier(0);   // keep every load of stage A above stage B
-#ifdef GTOP_STAMPS
-          if (j0 == 0 && s0 == 0) {
-            GTOP_STAMP(8);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            GTOP_STAMP(9);
-          }
-#endif
-          // Stage B: trilinear blend, penalty, accumulation.
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-          const R t = ts[c];
-          const bool live = lives[c];
-          const R *vel = vels[c], *acc3 = accs[c];
-          const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-          const R vn = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + (R)1e-5;  // :358
-          const R ivn = quick_rcp(vn);
-          R g3[3];
-          bool is_out;
-          const R dist = sdf_blend(taps[c], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
-          // samples past the loop bound of :353 and idle lanes contribute nothing:
-          // every term below carries a factor e
-          const R e = live ? penalty_exp((pen_d0 - dist) * pen_inv_r, expk) : (R)0;   // exp(-(d - d0)/r)
-          const R cd = pen_alpha * e;                  // :509
-          const R gd = pen_gd * e;                     // :514
-          R csum = wdt * (cd * vn);                    // :373, weighted as in :417-418
-          // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381)
-          const R f1 = is_out ? (R)0 : (wdt * a.res_inv) * (gd * cd * vn), f2 = wdt * (cd * ivn);   // 1/res: g3's unit
-          R w1[3], w2[3], w3[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            w1[k] = f1 * g3[k];
-            w2[k] = f2 * vel[k];
-            w3[k] = (R)0;
-          }
-          if (DYN && a.step == 2) {
-            // the block commented out at :383-407, formulas :517-535.  cv/ca
-            // in the gradient are the values left by the LAST axis of the
-            // cost loop, and there is no sign(v) factor — both as written.
-            R cv = (R)0, ca = (R)0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              cv = a.alpha_v * gexp((gabs(vel[k]) - a.v0) / a.r_v);
-              ca = a.alpha_a * gexp((gabs(acc3[k]) - a.a0) / a.r_a);
-              csum += (cv + ca) * vn * dt;       // wv = wa = 1 (:412)
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const R gv = (a.alpha_v / a.r_v) * gexp((gabs(vel[k]) - a.v0) / a.r_v);
-              const R ga = (a.alpha_a / a.r_a) * gexp((gabs(acc3[k]) - a.a0) / a.r_a);
-              w2[k] += (gv * vn + cv * (vel[k] * ivn) + ca * (vel[k] * ivn)) * dt;
-              w3[k] = (ga * vn) * dt;            // on T*V*V
-            }
-          }
-          if (DYN && !live) {
-            csum = (R)0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) w2[k] = w3[k] = (R)0;
-          }
-          // T = [1,t,..,t^5] (:544-551); T*V = [0,1,2t,3t^2,4t^3,5t^4]; T*V*V = [0,0,2,6t,12t^2,20t^3]
-          const R d2 = (R)2 * t, d3 = (R)3 * t2, d4 = (R)4 * t3, d5 = (R)5 * t4;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            R *ak = acc + 6 * k;
-            // two fused multiply-adds per entry
-            ak[0] += w1[k];
-            ak[1] = gfma(w1[k], t, ak[1] + w2[k]);
-            ak[2] = gfma(w1[k], t2, gfma(w2[k], d2, ak[2]));
-            ak[3] = gfma(w1[k], t3, gfma(w2[k], d3, ak[3]));
-            ak[4] = gfma(w1[k], t4, gfma(w2[k], d4, ak[4]));
-            ak[5] = gfma(w1[k], t5, gfma(w2[k], d5, ak[5]));
-            if (DYN) {
-              ak[2] += w3[k] * (R)2;
-              ak[3] += w3[k] * (R)6 * t;
-              ak[4] += w3[k] * (R)12 * t2;
-              ak[5] += w3[k] * (R)20 * t3;
-            }
-          }
-          acc[18] += csum;
-          }
-#ifdef GTOP_STAMPS
-          if (j0 == 0 && s0 == 0) {
-            asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[11]), "v"(acc[17]), "v"(acc[18]));
-            GTOP_STAMP(10);
-          }
-#endif
-        }
-        // A_s^-T on this lane's 18 accumulators (coefficient space -> [p0,pT,v0,vT,a0,aT]
-        // per axis), so that the reduction below already yields what the free
-        // variables gather; the map is linear, so it commutes with the sums.
-        {
-          const R T = Tseg, T2 = T * T, iT = fast_rcp(T);
-          const R iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            R *g = acc + 6 * k;
-            const R H3 = g[3] * iT3, H4 = g[4] * iT4, H5 = g[5] * iT5;
-            const R ap = (R)10 * H3 - (R)15 * H4 + (R)6 * H5;
-            const R o0 = g[0] - ap;
-            const R o2 = g[1] + T * ((R)-6 * H3 + (R)8 * H4 - (R)3 * H5);
-            const R o3 = T * ((R)-4 * H3 + (R)7 * H4 - (R)3 * H5);
-            const R o4 = (R)0.5 * g[2] + T2 * ((R)-1.5 * H3 + (R)1.5 * H4 - (R)0.5 * H5);
-            const R o5 = T2 * ((R)0.5 * H3 - H4 + (R)0.5 * H5);
-            g[0] = o0; g[1] = ap; g[2] = o2; g[3] = o3; g[4] = o4; g[5] = o5;
-          }
-        }
-#ifdef GTOP_STAMPS   // pin the sample arithmetic in front of the stamp
-        asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[11]), "v"(acc[17]), "v"(acc[18]));
-#endif
-        GTOP_STAMP(3);
-        if (LPS == 1) {
-          // one lane owns the whole segment: no cross-lane reduction
-          if (seg_ok) {
-#pragma unroll
-            for (int v = 0; v < 18; ++v) gseg[S * 18 + v] = Gs[S * 18 + v] + acc[v];
-            ccol[S] = acc[18];
-          }
-        } else {
-          // transpose-reduce over the LPS lanes of each segment through LDS, kRedChunk
-          // of the 19 values at a time (tile = kRedChunk rows of kRedStride elements)
-#pragma unroll
-          for (int c0 = 0; c0 < kRedVals; c0 += kRedChunk) {
-            const int cn = (kRedVals - c0) < kRedChunk ? (kRedVals - c0) : kRedChunk;
-#pragma unroll
-            for (int v = 0; v < kRedChunk; ++v)
-              if ((v < cn) & (lane < LPS * SPW)) myred[v * kRedStride + lane] = acc[c0 + v];
-            // The tile belongs to this wavefront alone (writers and readers are its own
-            // lanes), and a wavefront's LDS operations execute in order: no workgroup
-            // barrier, only a compiler-level ordering point.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#ifdef GTOP_STAMPS
-            if (s0 == 0 && c0 == 0) GTOP_STAMP(11);
-#endif
-            // each lane owns up to kRdr (segment slot, value) sums; all tile reads are
-            // issued before any result is stored (one LDS round trip, not kRdr)
-            constexpr int kRdr = (SPW * kRedChunk + 63) / 64;
-            R sums[kRdr];
-#pragma unroll
-            for (int u = 0; u < kRdr; ++u) {
-              const int r = lane + 64 * u;
-              const int rs = r / cn, v = r - rs * cn;   // (segment slot, value in chunk)
-              const int Sr = s0 + wave * SPW + rs;
-              const bool ok = (r < SPW * cn) & (Sr < nseg);
-              const R *col = myred + (ok ? v * kRedStride + rs * LPS : 0);
-              const R jerk = (ok & (c0 + v < 18)) ? Gs[Sr * 18 + c0 + v] : (R)0;
-              sums[u] = jerk + tree_sum<R, LPS>(col);
-            }
-#ifdef GTOP_STAMPS
-            if (s0 == 0 && c0 == 0) { asm volatile("" ::"v"(sums[0])); GTOP_STAMP(12); }
-#endif
-#pragma unroll
-            for (int u = 0; u < kRdr; ++u) {
-              const int r = lane + 64 * u;
-              const int rs = r / cn, v = r - rs * cn;
-              const int Sr = s0 + wave * SPW + rs;
-              if ((r < SPW * cn) & (Sr < nseg)) {
-                if (c0 + v < 18) gseg[Sr * 18 + c0 + v] = sums[u];
-                else ccol[Sr] = sums[u];
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // tile is rewritten by the next chunk / pass
-            __builtin_amdgcn_wave_barrier();
-          }
-        }
-        if constexpr (FIXED) break;   // TPBC m <= SPW segments: one pass
-      }
-    } else {
-      for (int q = tid; q < 18 * nseg; q += nthr) gseg[q] = Gs[q];   // |wc| < 1e-4: no collision term (:346)
-    }
-    __syncthreads();   // gseg / ccol of every wavefront are complete
-    GTOP_STAMP(4);
-
-    GTOP_STAMP(5);
-
-    // ---- phase 4: gather to the free variables, +1e-5 (:425-432); cost (:417-418) ----
-    {
-      R *gb = a.grad + (size_t)b0 * n;
-      R *gl = Gs;    // [TPB][n] gradient copy for the fused optimizer step (Gs is dead after phase 3)
-      R *fc = dts;   // [TPB]    cost copy (dts is dead after phase 2)
-      for (int q = tid; q < ntraj * n; q += nthr) {
-        int tl = 0, i = q;
-        if constexpr (TPBC == 2) {
-          tl = i >= n;
-          i -= tl * n;
-        } else if constexpr (!ONE) {
-          while (i >= n) { i -= n; ++tl; }
-        }
-        const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
-        const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
-        const R *gs = gseg + tl * m * 18;
-        const R v = gs[((wpt - 1) * 3 + axis) * 6 + 2 * der + 1] +   // end of segment wpt-1
-                    gs[(wpt * 3 + axis) * 6 + 2 * der];              // start of segment wpt
-        if (MMA) gl[q] = v + (R)1e-5;   // consumed by the update below; nothing leaves the chip
-        else gb[q] = v + (R)1e-5;
-        if constexpr (ONE && 9 * (SPW - 1) <= 64) break;   // n = 9(m-1) <= 64 free variables: one trip
-      }
-#ifdef GTOP_STAMPS
-      GTOP_STAMP(13);
-#endif
-      for (int tl = wave; tl < ntraj; tl += NW) {   // one wavefront reduction per trajectory
-        R part = (R)0;
-        if constexpr (ONE) {
-          if (lane < 3 * m) part = ws * csm[lane];
-          if (lane < m) part += ccol[lane];
-        } else {
-          for (int i = lane; i < 3 * m; i += 64) part += ws * csm[tl * 3 * m + i];
-          for (int i = lane; i < m; i += 64) part += ccol[tl * m + i];
-        }
-        part = wave_sum(part);
-        if (lane == 0) {
-          if (MMA) fc[tl] = part + (R)1e-3;
-          else a.cost[b0 + tl] = part + (R)1e-3;
-        }
-      }
-      if constexpr (MMA) {
-        __syncthreads();   // gl / fc complete
-        for (int tl = wave; tl < ntraj; tl += NW)
-          gtop_mma_update_trajectory(st, b0 + tl, n, lane, (double)fc[tl], reinterpret_cast<const double *>(gl) + tl * n);
-      }
-    }
-    GTOP_STAMP(6);
-    if constexpr (FIXED && !MMA) break;   // nothing follows: no group, no pass
-    __syncthreads();   // LDS is reused by the next pass / the next group of this block
-    }
-    if constexpr (FIXED) break;   // the launcher gives every group its own workgroup
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1139,13 +581,27 @@ struct GtopWaveConsts {
 // reject, asymptotes, stop rules, next trial point), evaluate again; cost and gradient never leave the chip.  One
 // wavefront owns the trajectory, so the loop needs no barrier at all.  MM = GtopNoMma: a plain evaluation.
 struct GtopNoMma {};
-// register budget (wavefronts per SIMD) of a variant: MINW, except that the optimizer loop on six samples per lane
-// keeps the one-sample-at-a-time structure of MINW = 3 on the two-wavefront budget (its update needs the room)
-template <typename MM, int SPL, int MINW>
-constexpr int gtop_wave_budget() { return (!std::is_same<MM, GtopNoMma>::value && SPL == 6) ? 2 : MINW; }
+// DYN compiles in the velocity / acceleration penalties the reference has commented out
+// (src/grad_traj_optimizer.cpp:383-407, formulas :517-535; they sit inside the collision sample loop, so DYN needs
+// COLLI; the launcher picks DYN only for enable_dyn at step 2, as the block's own `step == 2` test would).
+// LONG serves trajectories of more than 12 segments with the same wavefront: the segments go through the body 12 at a
+// time (five lanes per segment), every chunk leaves its 18 derivative-space rows in ITS columns of an LDS tile of
+// 5 m columns, and the free variables are gathered from the whole tile after the last chunk; the cost is a plain
+// wavefront sum of the lanes' accumulators.  Up to 227 segments (160 KB of LDS; 118 in the optimizer loop).
+// Register budget (wavefronts per SIMD) of a variant: MINW, except that the optimizer loop on six samples per lane
+// and the DYN bodies keep the one-sample-at-a-time structure of MINW = 3 on the two-wavefront budget (the update and
+// the extra penalty terms need the room).
+// (64-bit field indices — fields past 4 GiB — spill the 168-VGPR fp64 bodies at six samples per lane: two-wavefront budget)
+// (the same for the fp64 body that walks more than 12 segments in chunks: 19 spilled registers at 168)
+template <typename R, bool WIDE, typename MM, int SPL, int MINW, bool DYN, bool LONG>
+constexpr int gtop_wave_budget() {
+  return ((!std::is_same<MM, GtopNoMma>::value && SPL == 6) || DYN || ((WIDE || LONG) && sizeof(R) == 8 && SPL == 6)) ? 2
+                                                                                                                     : MINW;
+}
 
-template <typename R, bool WIDE, int SPL, int NT, bool COLLI, int MINW, typename MM = GtopNoMma>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(gtop_wave_budget<MM, SPL, MINW>())))
+template <typename R, bool WIDE, int SPL, int NT, bool COLLI, int MINW, typename MM = GtopNoMma, bool DYN = false,
+          bool LONG = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(gtop_wave_budget<R, WIDE, MM, SPL, MINW, DYN, LONG>())))
 gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df, const R *__restrict__ arg_T,
                       const R *__restrict__ arg_sdf, int arg_B, int arg_m, int arg_t_stride, int arg_nx, int arg_ny,
                       int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K, const MM st) {
@@ -1158,19 +614,25 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   constexpr int LPS = kSamples / SPL;   // lanes per segment
   constexpr int SPW = 64 / LPS;         // segment slots per wavefront
   constexpr int kStride = red_stride(SPL);
-  constexpr int kMV = SPL == 6 ? 128 : 64;   // rows of the optimizer loop's LDS vectors: n <= 45 resp. 99 variables
+  constexpr int kMVc = SPL == 6 ? 128 : 64;   // rows of the optimizer loop's LDS vectors: n <= 45 resp. 99 variables
   static_assert(SPL == 3 || SPL == 6, "10 or 5 lanes per segment");
   static_assert(SPL == 3 || MINW >= 3, "six samples per lane: one (pair) at a time only");
-  static_assert(!MMA || SPL == 3 || !WIDE, "the six-samples-per-lane optimizer loop: 32-bit field offsets");
   static_assert(NT == 1 || NT == 2, "one or two trajectories per wavefront");
+  static_assert(!LONG || (SPL == 6 && NT == 1), "more than 12 segments: five lanes per segment, one trajectory");
+  static_assert(!DYN || (COLLI && MINW >= 3), "the velocity/acceleration block lives in the sample loop, one sample at a time");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);   // [19][kStride] (+ [kRounds*64] gradient for the optimizer update)
   GTOP_STAMP(0);
   GTOP_STAMP_HWID();
   const int lane = threadIdx.x;
   const int m = a.m, ndp = 3 * m - 3, n = 3 * ndp;
-  __builtin_assume(m >= 2 && NT * m <= SPW);
+  if constexpr (LONG) __builtin_assume(m > SPW);
+  else __builtin_assume(m >= 2 && NT * m <= SPW);
   __builtin_assume(lane >= 0 && lane < 64);
+  const int tstride = LONG ? ((LPS * m) | 1) : kStride;    // row stride of the tile (LONG: 5 m columns, made odd)
+  const int kMV = LONG ? ((n + 63) & ~63) : kMVc;          // rows of the optimizer loop's LDS vectors
+  const int nchunks = LONG ? (m + SPW - 1) / SPW : 1;
+  constexpr int kTileRows = LONG ? 18 : kRedVals;          // (LONG sums the cost in registers)
   GTOP_STAMP(1);
 
   // XCD-aware order (see gtop_eval_kernel): XCD x gets the x-th contiguous eighth of the batch
@@ -1190,7 +652,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     tl = s >= m;
     s -= tl * m;
   }
-  const bool seg_ok = grp_ok & (slot < NT * m) & (b0 + tl < a.B);
+  bool seg_ok = grp_ok & (slot < NT * m) & (b0 + tl < a.B);   // (LONG: set per chunk, below)
   if (!seg_ok) { tl = 0; s = 0; }   // idle lanes shadow the first segment: finite data, results never read
 
   unsigned long long t_launch = 0ull;
@@ -1208,7 +670,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   [[maybe_unused]] GtopMmaScalars msc = {};
   [[maybe_unused]] bool mma_live = false;
   if constexpr (MMA) {
-    mv = reinterpret_cast<double *>(tile) + kRedVals * kStride + 128;
+    mv = reinterpret_cast<double *>(tile) + kTileRows * tstride + (LONG ? kMV : 128);
     // (the evaluation reads its inputs from here too — the trial point, and Df and T staged once behind the
     // vectors — so a pass has no global load but the distance-field corners, and no global store at all)
     mvecs = GtopMmaVecs{mv, mv + kMV, mv + 2 * kMV, mv + 3 * kMV, mv + 4 * kMV, mv + 5 * kMV, mv + 6 * kMV, mv + 7 * kMV,
@@ -1217,7 +679,11 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     if (mma_live) {
       const size_t o = (size_t)b0 * n;
       if (lane < 18) mv[8 * kMV + lane] = a.Df[(size_t)b0 * 18 + lane];
-      if (lane < m) mv[8 * kMV + 18 + lane] = a.T[(size_t)b0 * a.t_stride + lane];
+      if constexpr (LONG) {
+        for (int j = lane; j < m; j += 64) mv[8 * kMV + 18 + j] = a.T[(size_t)b0 * a.t_stride + j];
+      } else {
+        if (lane < m) mv[8 * kMV + 18 + lane] = a.T[(size_t)b0 * a.t_stride + lane];
+      }
       if (st.x0_init) {   // (uniform) a fresh problem: mma_init_kernel's arithmetic, straight into LDS
         msc = GtopMmaScalars{1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0};
         for (int j = lane; j < n; j += 64) {
@@ -1258,6 +724,17 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       break;
     }
   }
+  [[maybe_unused]] R cost_run = (R)0;   // LONG: this lane's share of the cost over its chunks
+  constexpr int kRounds = LONG ? 1 : (NT * 9 * (SPW / NT - 1) + 63) / 64;
+  int offA[kRounds], offB[kRounds];     // (filled below, while the inputs are on their way)
+  bool okq[kRounds];
+  bool cost_lane = false;
+  for (int ch = 0; ch < nchunks; ++ch) {
+  if constexpr (LONG) {
+    s = ch * SPW + slot;
+    seg_ok = grp_ok & (slot < SPW) & (s < m);
+    if (!seg_ok) s = 0;
+  }
   // ---- inputs: two waypoints' (p, v, a) per axis and T_s, straight from HBM/L2 (the optimizer loop: from LDS) ----
   // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
   const R *xb = xsrc + (size_t)b0 * n + tl * n;      // this lane's trajectory (b0: wave-uniform)
@@ -1288,11 +765,8 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // Where this lane's free variable(s) will be summed from at the very end (index arithmetic done here, while
   // the inputs are on their way): free variable = end of segment wpt-1 (entry 2 der + 1) + start of segment
   // wpt (entry 2 der)  (:425-432); tile[v][lane] holds entry v of lane's segment.
-  constexpr int kRounds = (NT * 9 * (SPW / NT - 1) + 63) / 64;
-  int offA[kRounds], offB[kRounds];
-  bool okq[kRounds];
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
+  for (int r = 0; r < (LONG ? 0 : kRounds); ++r) {
     const int qi = lane + 64 * r;
     int tq = 0, i = qi;
     if constexpr (NT == 2) {
@@ -1316,7 +790,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // the same way (a trajectory's result must not depend on its place in the pair).
   const int cs = lane - 48;
   const int ct = NT == 2 ? cs >> 3 : 0, csi = NT == 2 ? cs & 7 : cs;   // trajectory, segment
-  const bool cost_lane = (cs >= 0) & (csi < m);
+  cost_lane = !LONG & (cs >= 0) & (csi < m);
   if (cost_lane) offA[kRounds - 1] = 18 * kStride + (ct * m + csi) * LPS;
   const R ws = a.ws;   // the launcher has applied :412-415 (step 1 -> ws = 0): `step` is not read here
   const R wc = a.wc;
@@ -1389,23 +863,27 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // sample COUNT depends on the accumulated value) replay the reference's addition chain.
     const bool tiny_T = T < (R)0.0301;
     const bool any_tiny = __ballot(tiny_T) != 0ull;   // wave-uniform, rare
-    auto sample_time = [&](int j, R &t, R &awj) {
+    // (sdt: the sample's own dt, zero past the loop bound — the factor every DYN term carries; unused otherwise)
+    auto sample_time = [&](int j, R &t, R &awj, R &sdt) {
       t = (R)(li + j * LPS) * dt + (R)1e-3;
       awj = pen_alpha * wdt;
+      sdt = dt;
       if (any_tiny) {
         if (tiny_T) {
           const R dtq = T / (R)30.0;   // the quotient proper, :351
           t = (R)1e-3;
           for (int i = 0; i < li + j * LPS; ++i) t += dtq;
           awj = (t < T) ? pen_alpha * (wc * dtq) : (R)0;
+          sdt = (t < T) ? dtq : (R)0;
         }
       }
     };
     constexpr int NTS = (MINW <= 2) ? SPL : 1;   // latency regime: all sample times before the first load
     R ts[NTS], aw[NTS];
+    [[maybe_unused]] R sdts[NTS];
     if constexpr (MINW <= 2) {
 #pragma unroll
-      for (int j = 0; j < SPL; ++j) sample_time(j, ts[j], aw[j]);
+      for (int j = 0; j < SPL; ++j) sample_time(j, ts[j], aw[j], sdts[j]);
     }
     // The samples of a lane go through two stages, CH at a time.  Latency regime (MINW = 2): CH = SPL, all 12 corner
     // loads of the lane in flight at once, the jerk term and the speeds computed behind them, the order pinned by
@@ -1431,11 +909,13 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       for (int v = 0; v < kRedVals; ++v) acc2[v] = (f2){(float)acc[v], 0.0f};
 #pragma unroll 1
       for (int jj = 0; jj < SPL; jj += 2) {
-        R tA, tB, awA, awB;
-        sample_time(jj, tA, awA);
-        sample_time(jj + 1, tB, awB);
-        sample_pair_f32<false, WIDE>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, (f2){(float)tA, (float)tB},
-                                     awA != (R)0, awB != (R)0, (float)wdt, (float)dt, acc2);
+        R tA, tB, awA, awB, sdA, sdB;
+        sample_time(jj, tA, awA, sdA);
+        sample_time(jj + 1, tB, awB, sdB);
+        // (live = inside the loop bound of :353; without DYN every term carries alpha, so alpha*wc*dt != 0 says the same)
+        sample_pair_f32<DYN, WIDE>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, (f2){(float)tA, (float)tB},
+                                   DYN ? sdA != (R)0 : awA != (R)0, DYN ? sdB != (R)0 : awB != (R)0, (float)wdt,
+                                   (float)dt, acc2);
       }
 #pragma unroll
       for (int v = 0; v < kRedVals; ++v) acc[v] = (R)(acc2[v].x + acc2[v].y);
@@ -1445,9 +925,10 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     for (int j0 = 0; j0 < SPL; j0 += CH) {
       // stage A: positions, index arithmetic, corner loads
       R vels[CH][3];
+      [[maybe_unused]] R accs[CH][3];
       SdfTap<R> taps[CH];
       gtop_d2 raw[ASMLD ? CH : 1][4];
-      if constexpr (MINW > 2) sample_time(j0, ts[0], aw[0]);
+      if constexpr (MINW > 2) sample_time(j0, ts[0], aw[0], sdts[0]);
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const R t = ts[MINW <= 2 ? j0 + c : 0];
@@ -1459,6 +940,8 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
           // :457-465 / :477-485 (sums in the reference's order), then the float round trip
           pos[k] = round_through_float(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
           vels[c][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
+          if constexpr (DYN)   // getAccelerationFromCoeff, :491-505 (through `float` like the other two)
+            accs[c][k] = round_through_float((R)2 * q[k][2] + K.k6 * q[k][3] * t + (R)12 * q[k][4] * t2 + (R)20 * q[k][5] * t3);
         }
         if constexpr (ASMLD) taps[c] = sdf_issue_asm(a, mapbox, pos[0], pos[1], pos[2], raw[c]);
         else taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
@@ -1514,6 +997,29 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381); gd of :514
         const R f1 = is_out ? (R)0 : ((pen_gd * a.res_inv) * e) * cv, f2 = cdw * ivn;
         const R d2 = (R)2 * t, d3 = K.k3 * t2, d4 = (R)4 * t3, d5 = K.k5 * t4;
+        [[maybe_unused]] R dw2[3], dw3[3];
+        if constexpr (DYN) {
+          // The block commented out at :383-407 with the formulas of :517-535: per axis cv = alpha_v exp((|v| - v0)/r_v),
+          // ca likewise on the acceleration; cost += (cv + ca) |v| dt per axis (wv = wa = 1, :412); in the gradient the
+          // velocity row gets gv |v| + (cv + ca) v/|v| and the acceleration row ga |v|, where cv, ca are the values
+          // the cost loop LEFT BEHIND — the last axis's — and there is no sign(v) factor: both as written.
+          const R sdt = sdts[MINW <= 2 ? j0 + c : 0];   // this sample's dt; 0 past the loop bound of :353
+          const R *acc3 = accs[c];
+          R ev[3], ea[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            ev[k] = penalty_exp((gabs(vel[k]) - a.v0) * a.inv_r_v, expk);
+            ea[k] = penalty_exp((gabs(acc3[k]) - a.a0) * a.inv_r_a, expk);
+          }
+          const R csum_dyn = a.alpha_v * ((ev[0] + ev[1]) + ev[2]) + a.alpha_a * ((ea[0] + ea[1]) + ea[2]);
+          acc[18] = gfma(csum_dyn * vn, sdt, acc[18]);
+          const R clast = (a.alpha_v * ev[2] + a.alpha_a * ea[2]) * ivn;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            dw2[k] = (a.gv_scale * ev[k] * vn + clast * vel[k]) * sdt;
+            dw3[k] = (a.ga_scale * ea[k] * vn) * sdt;          // on T*V*V = [0, 0, 2, 6t, 12t^2, 20t^3]
+          }
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const R w1k = f1 * g3[k], w2k = f2 * vel[k];
@@ -1524,6 +1030,13 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
           ak[3] = gfma(w1k, t3, gfma(w2k, d3, ak[3]));
           ak[4] = gfma(w1k, t4, gfma(w2k, d4, ak[4]));
           ak[5] = gfma(w1k, t5, gfma(w2k, d5, ak[5]));
+          if constexpr (DYN) {
+            ak[1] += dw2[k];
+            ak[2] = gfma(dw2[k], d2, gfma(dw3[k], (R)2, ak[2]));
+            ak[3] = gfma(dw2[k], d3, gfma(dw3[k] * K.k6, t, ak[3]));
+            ak[4] = gfma(dw2[k], d4, gfma(dw3[k] * (R)12, t2, ak[4]));
+            ak[5] = gfma(dw2[k], d5, gfma(dw3[k] * (R)20, t3, ak[5]));
+          }
         }
       }
       if constexpr (CH != SPL) __builtin_amdgcn_sched_barrier(0);   // keep the samples apart: one sample's corners live
@@ -1557,16 +1070,48 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     g[0] = o0; g[1] = ap; g[2] = o2; g[3] = o3; g[4] = o4; g[5] = o5;
   }
   // ---- the one LDS round trip: tile[v][lane], then each free variable (and each segment's cost) sums its entries ----
+  if constexpr (LONG) {
+    if (seg_ok) {   // this chunk's columns of the 5 m-column tile
+      const int col = s * LPS + li;
+#pragma unroll
+      for (int v = 0; v < 18; ++v) tile[v * tstride + col] = acc[v];
+      cost_run += acc[18];
+    }
+  } else {
   if (lane < LPS * SPW) {
 #pragma unroll
     for (int v = 0; v < kRedVals; ++v) tile[v * kStride + lane] = acc[v];   // (columns of idle slots are never read)
   }
+  }
   GTOP_STAMP(8);   // A^-T + tile writes issued
   GTOP_STAMP(9);
+  }   // chunk
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
   __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
   R csum_seg = (R)0;
-  R *gl = tile + kRedVals * kStride;   // [kRounds*64]: the gradient for the optimizer update (MMA only)
+  R *gl = tile + kTileRows * tstride;   // [kRounds*64] (LONG: [kMV]): the gradient for the optimizer update (MMA only)
+  if constexpr (LONG) {
+    // every free variable = end of segment wpt-1 + start of segment wpt (:425-432), straight from the whole tile
+    for (int qi = lane; qi < n; qi += 64) {
+      const int axis = (qi >= ndp) + (qi >= 2 * ndp), c = qi - axis * ndp;
+      const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
+      const int rowB = axis * 6 + 2 * der;
+      const R sa = tree_sum<R, LPS>(tile + (rowB + 1) * tstride + (wpt - 1) * LPS),
+              sb = tree_sum<R, LPS>(tile + rowB * tstride + wpt * LPS);
+      if constexpr (MMA) gl[qi] = (sa + sb) + K.eps;
+      else if (grp_ok) a.grad[(size_t)b0 * n + qi] = (sa + sb) + K.eps;
+    }
+    const R ctot = gtop_wave_sum(cost_run) + (R)1e-3;   // (:417-418; every lane gets the sum)
+    if constexpr (MMA) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
+      __builtin_amdgcn_wave_barrier();
+      gtop_mma_update_core(st, mvecs, msc, n, lane, (double)ctot, reinterpret_cast<const double *>(gl));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is rewritten by the next evaluation
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      if (grp_ok & (lane == 0)) a.cost[b0] = ctot;
+    }
+  } else {
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const R sa = tree_sum<R, LPS>(tile + offA[r]), sb = tree_sum<R, LPS>(tile + offB[r]);
@@ -1606,6 +1151,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
     }
   }
+  }   // !LONG
   GTOP_STAMP(10);   // gradient stored (issued)
 #ifdef GTOP_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1640,180 +1186,134 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
 
 }  // namespace
 
-size_t gtop_eval_smem_bytes(int m, int waves, int tpb, int spl, size_t elem, int red_rows) {
-  const size_t MS = (size_t)tpb * m;
-  const size_t elems = MS + 18 * MS * 2 + 3 * MS + MS + (size_t)waves * (red_rows > 0 ? red_rows : kRedChunkFull) * red_stride(spl);
-  return elems * elem;
-}
-
-int gtop_eval_segments_per_wave(int spl) { return 64 / (kSamples / spl); }
-
 // WIDE = false needs 24-bit row/column counts and a field below 4 GiB (corner_loads)
 bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
   const unsigned long long nvox = (unsigned long long)nx * ny * nz;
   return (unsigned long long)nx * ny < (1ull << 24) && nz < (1 << 24) && (nvox + 2) * elem < (1ull << 32);
 }
 
-#ifndef GTOP_WAVE_KERNEL
-#define GTOP_WAVE_KERNEL 1
-#endif
-#define GTOP_WAVE_KERNEL_DEFAULT GTOP_WAVE_KERNEL
-#ifndef GTOP_WAVE_SPL6
-#define GTOP_WAVE_SPL6 1
-#endif
-#define GTOP_WAVE_SPL6_DEFAULT GTOP_WAVE_SPL6
-
-// the specialised straight-line bodies: one wavefront = one whole trajectory (SPL 3 or 6) or two (SPL 6)
-template <typename R>
-static bool gtop_fixed_body_ok(const GtopKernelArgs<R> &args, int waves, int spl, int grid) {
-  const int groups = (args.B + args.tpb - 1) / args.tpb;
-  return (spl == 3 || spl == 6) && waves == 1 && args.m >= 2 &&
-         args.tpb * args.m <= gtop_eval_segments_per_wave(spl) &&
-         grid == 8 * ((groups + 7) / 8);   // (no grid-stride loop in those bodies)
-}
-
-template <typename R, bool DYN, bool MMA, bool WIDE>
-static hipError_t launch_spl(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, int grid,
-                             size_t smem /* of the generic body */, hipStream_t stream, bool wave_ok) {
-  void (*kern)(const GtopKernelArgs<R>, const GtopMmaState) = nullptr;
-  const bool fixed_ok = gtop_fixed_body_ok(args, waves, spl, grid);
-  // A field that outgrows the 256 MB Infinity Cache is served by HBM; a fourth wavefront per SIMD then only
-  // adds L2 misses (measured at 400^3 fp64, m = 12: 47 us with the generic three-wavefront body, 52 us with
-  // four, 50 us with the specialised body held at three), so the SPL = 6 specialisations are for resident fields.
-  const unsigned long long field_bytes = (unsigned long long)args.nx * args.ny * args.nz * sizeof(R);
-  const bool resident = field_bytes <= (256ull << 20);
-  const bool one = fixed_ok && args.tpb == 1 && (spl == 3 || resident);
-  const bool two = fixed_ok && args.tpb == 2 && spl == 6 && !MMA && resident;
-  if (!MMA && spl == 6 && (one || two))   // their tile
-    smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R), red_chunk(sizeof(R), 6, args.tpb));
-
 #ifndef GTOP_WAVE_MINW3_FROM
 #define GTOP_WAVE_MINW3_FROM 3072   // batches that put a third wavefront on a SIMD (1 024 SIMDs)
 #endif
 
-  if constexpr (GTOP_WAVE_KERNEL && !DYN) {
-    // gtop_eval_wave_kernel: whole trajectories per wavefront, no workgroup barrier.  spl 3: one trajectory of up to
-    // 6 segments (latency variant below GTOP_WAVE_MINW3_FROM trajectories) — with or without the optimizer loop;
-    // spl 6: one trajectory of up to 12 segments, or two of up to 6 (fp32: packed sample pairs).
-    // wave_ok = false (the optimizer's separate-update mode) keeps a plain evaluation on the body its fused modes
-    // run: the wave kernel exactly where they run it (spl 3, one trajectory per wavefront).
-    GtopKernelArgs<R> wa = args;
-    if (wa.step == 1) wa.ws = (R)0;   // :412-415, applied here so that the kernel need not fetch `step`
-    const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
-    // (64-bit field indices — fields past 4 GiB — cost the 168-VGPR fp64 body 14 spilled registers: those stay on
-    // the two-wavefront budget)
-    const bool three = args.B >= GTOP_WAVE_MINW3_FROM && !(WIDE && sizeof(R) == 8);
-    // tile + the optimizer's gradient rows (+ its state: 8 vectors of 64, Df, T; gtop_eval_wave_kernel)
-    const size_t wsmem = (kRedVals * red_stride(spl) + 128 + (MMA ? 8 * (spl == 6 ? 128 : 64) + 32 : 0)) * sizeof(R);
-    if constexpr (MMA) {
-      if constexpr (sizeof(R) == 8) {
-        if (one && spl == 3) {
-          // (two wavefronts per SIMD at every batch size: the update's working set spills a 168-VGPR budget)
-          auto wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2, GtopMmaState>
-                          : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2, GtopMmaState>;
-          hipLaunchKernelGGL(wk, dim3(grid), dim3(64), wsmem, stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B, wa.m, wa.t_stride,
-                             wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{}, st);
-          return hipGetLastError();
-        }
-        if constexpr (!WIDE) {
-          if (GTOP_WAVE_SPL6 && fixed_ok && spl == 6 && args.tpb == 1) {
-            // 7 .. 12 segments: one trajectory per wavefront at five lanes per segment, one sample at a time
-            auto wk = colli ? gtop_eval_wave_kernel<R, false, 6, 1, true, 3, GtopMmaState>
-                            : gtop_eval_wave_kernel<R, false, 6, 1, false, 3, GtopMmaState>;
-            hipLaunchKernelGGL(wk, dim3(grid), dim3(64), wsmem, stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B, wa.m,
-                               wa.t_stride, wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{}, st);
-            return hipGetLastError();
-          }
-        }
-      }
-    } else {
-      constexpr int kW6 = 3;   // register budget of the spl 6 variants: wavefronts per SIMD (fp32 at 4 spills 25 VGPRs)
-      void (*wk)(const R *, const R *, const R *, const R *, int, int, int, int, int, int, const GtopKernelArgs<R>,
-                 const GtopWaveConsts<R>, const GtopNoMma) = nullptr;
-      if (one && spl == 3) {
-        wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 2> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 2>;
-        if (three) wk = colli ? gtop_eval_wave_kernel<R, WIDE, 3, 1, true, 3> : gtop_eval_wave_kernel<R, WIDE, 3, 1, false, 3>;
-      } else if (GTOP_WAVE_SPL6 && (wave_ok || (sizeof(R) == 8 && !WIDE)) && fixed_ok && spl == 6 && args.tpb == 1) {
-        // (wave_ok = false: exactly where the fused optimizer modes run their five-lanes-per-segment loop, above)
-        wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 1, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 1, false, kW6>;
-      } else if (GTOP_WAVE_SPL6 && wave_ok && fixed_ok && spl == 6 && args.tpb == 2) {
-        wk = colli ? gtop_eval_wave_kernel<R, WIDE, 6, 2, true, kW6> : gtop_eval_wave_kernel<R, WIDE, 6, 2, false, kW6>;
-      }
-      if (wk) {
-        hipLaunchKernelGGL(wk, dim3(grid), dim3(64), wsmem, stream, wa.x, wa.Df, wa.T, wa.sdf, wa.B, wa.m, wa.t_stride,
-                           wa.nx, wa.ny, wa.nz, wa, GtopWaveConsts<R>{}, GtopNoMma{});
-        return hipGetLastError();
-      }
-    }
+// LDS of one workgroup (= one wavefront): the tile, the optimizer's gradient rows and — for the optimizer loop — its
+// state (eight vectors, Df, T).  Mirrors the pointer arithmetic of gtop_eval_wave_kernel.
+static size_t wave_lds_bytes(const GtopEvalPlan &p, int m, size_t elem, bool mma) {
+  if (!p.is_long) {
+    const int kmv = p.spl == 6 ? 128 : 64;
+    return (size_t)(kRedVals * red_stride(p.spl) + 128 + (mma ? 8 * kmv + 32 : 0)) * elem;
   }
-  if constexpr (MMA) {   // the fused optimizer step is built for the geometries the auto rules pick
-    switch (spl) {
-      case 1: kern = gtop_eval_kernel<R, DYN, 1, true, WIDE, 0>; break;
-      case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, true, WIDE, 1> : gtop_eval_kernel<R, DYN, 3, true, WIDE, 0>; break;
-      case 6: kern = one ? gtop_eval_kernel<R, DYN, 6, true, WIDE, 1> : gtop_eval_kernel<R, DYN, 6, true, WIDE, 0>; break;
-      default: return hipErrorInvalidValue;
+  const int n = 9 * (m - 1), kmv = (n + 63) & ~63, tstride = ((kSamples / 6) * m) | 1;
+  return ((size_t)18 * tstride + (mma ? (size_t)9 * kmv + 18 + m + 8 : 0)) * elem;
+}
+
+// The launch rule (measured).  Up to 6 segments: ten lanes per segment, one wavefront per
+// trajectory, at EVERY batch size in fp64 and up to 8 192 trajectories in fp32, where the packed-fp32 kernel with two
+// trajectories per wavefront at five lanes per segment takes over.  7 .. 12 segments: five lanes per segment, one
+// trajectory per wavefront.  Past 12: the same wavefront walks the segments 12 at a time (LONG).  The optimizer loop
+// always has one trajectory per wavefront.  pinned_spl = 3 or 6 overrides the lanes-per-segment choice where it can
+// be honoured (3: up to 6 segments).
+bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimizer, GtopEvalPlan *plan) {
+  if (m < 2 || (pinned_spl != 0 && pinned_spl != 3 && pinned_spl != 6)) return false;
+  GtopEvalPlan p{};
+  if (m <= 6) p.spl = pinned_spl ? pinned_spl : ((elem == 4 && B >= 8192 && !for_optimizer) ? 6 : 3);
+  else if (pinned_spl == 3) return false;   // ten lanes per segment: six segments fill the wavefront
+  else p.spl = 6;
+  p.is_long = m > 12;
+  p.nt = (p.spl == 6 && 2 * m <= 12 && !for_optimizer) ? 2 : 1;
+  if (wave_lds_bytes(p, m, elem, for_optimizer) > 160u * 1024u) return false;   // ~200 segments
+  *plan = p;
+  return true;
+}
+
+namespace {
+
+template <typename R, typename MM>
+using WaveKernelFn = void (*)(const R *, const R *, const R *, const R *, int, int, int, int, int, int,
+                              const GtopKernelArgs<R>, const GtopWaveConsts<R>, const MM);
+
+// one geometry: the collision-free, the ordinary and the DYN instantiation (DYN: one sample at a time, MINW >= 3)
+template <typename R, bool WIDE, int SPL, int NT, int MINW, typename MM, bool LONG>
+static WaveKernelFn<R, MM> pick_body(bool colli, bool dyn) {
+  if (!colli) return gtop_eval_wave_kernel<R, WIDE, SPL, NT, false, MINW, MM, false, LONG>;   // (:346: no sample loop, no DYN)
+  if (dyn) return gtop_eval_wave_kernel<R, WIDE, SPL, NT, true, (MINW < 3 ? 3 : MINW), MM, true, LONG>;
+  return gtop_eval_wave_kernel<R, WIDE, SPL, NT, true, MINW, MM, false, LONG>;
+}
+
+template <typename R, bool WIDE, typename MM>
+static WaveKernelFn<R, MM> pick_geometry(const GtopEvalPlan &p, int B, bool colli, bool dyn) {
+  constexpr bool MMA = !std::is_same<MM, GtopNoMma>::value;
+  if (p.is_long) return pick_body<R, WIDE, 6, 1, 3, MM, true>(colli, dyn);
+  if (p.spl == 3) {
+    // latency variant (every corner load of a lane in flight, 252 VGPRs) up to the batch that puts a third wavefront
+    // on a SIMD; the optimizer loop at every size (its update's working set spills a 168-VGPR budget); 64-bit field
+    // indices cost the 168-VGPR fp64 body 14 spilled registers: those stay on the two-wavefront budget too
+    if constexpr (!MMA && !(WIDE && sizeof(R) == 8)) {
+      if (B >= GTOP_WAVE_MINW3_FROM) return pick_body<R, WIDE, 3, 1, 3, MM, false>(colli, dyn);
     }
-  } else {
-    switch (spl) {
-      case 1: kern = gtop_eval_kernel<R, DYN, 1, false, WIDE, 0>; break;
-      case 2: kern = gtop_eval_kernel<R, DYN, 2, false, WIDE, 0>; break;
-      case 3: kern = one ? gtop_eval_kernel<R, DYN, 3, false, WIDE, 1> : gtop_eval_kernel<R, DYN, 3, false, WIDE, 0>; break;
-      case 5: kern = gtop_eval_kernel<R, DYN, 5, false, WIDE, 0>; break;
-      case 6: kern = one ? gtop_eval_kernel<R, DYN, 6, false, WIDE, 1>
-                         : (two ? gtop_eval_kernel<R, DYN, 6, false, WIDE, 2> : gtop_eval_kernel<R, DYN, 6, false, WIDE, 0>);
-              break;
-      case 10: kern = gtop_eval_kernel<R, DYN, 10, false, WIDE, 0>; break;
-      case 15: kern = gtop_eval_kernel<R, DYN, 15, false, WIDE, 0>; break;
-      case 30: kern = gtop_eval_kernel<R, DYN, 30, false, WIDE, 0>; break;
-      default: return hipErrorInvalidValue;
-    }
+    return pick_body<R, WIDE, 3, 1, 2, MM, false>(colli, dyn);
   }
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if constexpr (!MMA) {
+    if (p.nt == 2) return pick_body<R, WIDE, 6, 2, 3, MM, false>(colli, dyn);
+  }
+  return pick_body<R, WIDE, 6, 1, 3, MM, false>(colli, dyn);
+}
+
+// one launch covers up to 2^25 wavefronts (grid x 64 threads stays below 2^32); a larger batch goes in slices
+constexpr int kMaxGroupsPerLaunch = 1 << 25;
+
+template <typename R, typename MM>
+static hipError_t launch_wave(const GtopKernelArgs<R> &args, const MM &st, const GtopEvalPlan &plan, bool dyn,
+                              hipStream_t stream) {
+  constexpr bool MMA = !std::is_same<MM, GtopNoMma>::value;
+  if (args.B <= 0) return hipSuccess;
+  GtopKernelArgs<R> wa = args;
+  if (wa.step == 1) wa.ws = (R)0;   // :412-415, applied here so that the kernel need not fetch `step`
+  const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
+  dyn = dyn && wa.step == 2;        // the commented-out block's own test (:383)
+  const bool wide = !gtop_field_is_narrow(wa.nx, wa.ny, wa.nz, sizeof(R));
+  const WaveKernelFn<R, MM> kern = wide ? pick_geometry<R, true, MM>(plan, wa.B, colli, dyn)
+                                        : pick_geometry<R, false, MM>(plan, wa.B, colli, dyn);
+  const size_t smem = wave_lds_bytes(plan, wa.m, sizeof(R), MMA);
+  if (smem > 160u * 1024u) return hipErrorInvalidValue;
+  if (smem > 64u * 1024u) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), smem, stream, args, st);
-  return hipGetLastError();
+  const int n = 9 * (wa.m - 1);
+  const long long per_launch = (long long)kMaxGroupsPerLaunch * plan.nt;
+  if (MMA && wa.B > per_launch) return hipErrorInvalidValue;   // (the optimizer's state for 2^25 trajectories is 90 GB)
+  for (long long b0 = 0; b0 < args.B; b0 += per_launch) {
+    GtopKernelArgs<R> s = wa;
+    s.B = (int)((args.B - b0) < per_launch ? (args.B - b0) : per_launch);
+    s.x = wa.x + (size_t)b0 * n;
+    s.Df = wa.Df + (size_t)b0 * 18;
+    s.T = wa.T + (size_t)b0 * wa.t_stride;
+    s.cost = wa.cost ? wa.cost + b0 : nullptr;
+    s.grad = wa.grad ? wa.grad + (size_t)b0 * n : nullptr;
+    const int groups = (s.B + plan.nt - 1) / plan.nt;
+    const int grid = 8 * ((groups + 7) / 8);   // the kernel deals its workgroups over 8 XCD-contiguous ranges
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), smem, stream, s.x, s.Df, s.T, s.sdf, s.B, s.m, s.t_stride, s.nx, s.ny,
+                       s.nz, s, GtopWaveConsts<R>{}, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
-template <typename R, bool MMA>
-static hipError_t launch_any(const GtopKernelArgs<R> &args, const GtopMmaState &st, int waves, int spl, bool dyn,
-                             int max_blocks, hipStream_t stream, bool wave_ok = true) {
-  if (args.B <= 0) return hipSuccess;
-  const size_t smem = gtop_eval_smem_bytes(args.m, waves, args.tpb, spl, sizeof(R));
-  const int groups = (args.B + args.tpb - 1) / args.tpb;
-  const int vblocks = 8 * ((groups + 7) / 8);   // the kernel walks 8 XCD-contiguous ranges
-  const int grid = vblocks < max_blocks ? vblocks : max_blocks;
-  const bool wide = !gtop_field_is_narrow(args.nx, args.ny, args.nz, sizeof(R));
-  if (wide)
-    return dyn ? launch_spl<R, true, MMA, true>(args, st, waves, spl, grid, smem, stream, wave_ok)
-               : launch_spl<R, false, MMA, true>(args, st, waves, spl, grid, smem, stream, wave_ok);
-  return dyn ? launch_spl<R, true, MMA, false>(args, st, waves, spl, grid, smem, stream, wave_ok)
-             : launch_spl<R, false, MMA, false>(args, st, waves, spl, grid, smem, stream, wave_ok);
-}
+}  // namespace
 
 template <typename R>
-hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, int waves, int spl, bool dyn,
-                            int max_blocks, hipStream_t stream, bool wave_kernel_ok) {
-  const GtopMmaState none{};
-  return launch_any<R, false>(args, none, waves, spl, dyn, max_blocks, stream, wave_kernel_ok);
+hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &plan, bool dyn, hipStream_t stream) {
+  return launch_wave<R, GtopNoMma>(args, GtopNoMma{}, plan, dyn, stream);
 }
 
-bool gtop_eval_mma_is_wave_loop(const GtopKernelArgs<double> &args, int waves, int spl, bool dyn, int max_blocks) {
-  if (args.B <= 0 || dyn || !GTOP_WAVE_KERNEL_DEFAULT) return false;
-  const int groups = (args.B + args.tpb - 1) / args.tpb;
-  const int vblocks = 8 * ((groups + 7) / 8);
-  const int grid = vblocks < max_blocks ? vblocks : max_blocks;
-  // launch_spl: `one && spl == 3`, or the six-samples-per-lane loop (32-bit field offsets only)
-  if (!gtop_fixed_body_ok(args, waves, spl, grid) || args.tpb != 1) return false;
-  return spl == 3 || (GTOP_WAVE_SPL6_DEFAULT && spl == 6 && gtop_field_is_narrow(args.nx, args.ny, args.nz, sizeof(double)));
-}
-
-// cost/gradient at st.xcur + the MMA update, one launch (fp64; spl 1, 3 or 6)
-hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, int waves, int spl,
-                                bool dyn, int max_blocks, hipStream_t stream) {
-  return launch_any<double, true>(args, st, waves, spl, dyn, max_blocks, stream);
+// the optimizer loop: st.iters evaluations at st.xcur, each followed by the CCSA-MMA update, in one launch (fp64)
+hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
+                                bool dyn, hipStream_t stream) {
+  if (plan.nt != 1) return hipErrorInvalidValue;
+  return launch_wave<double, GtopMmaState>(args, st, plan, dyn, stream);
 }
 
 #ifdef GTOP_STAMPS
@@ -1822,8 +1322,8 @@ extern "C" int gtop_debug_read_stamps(unsigned long long *out /*4096*16*/) {
 }
 #endif
 
-template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, int, int, bool, int, hipStream_t, bool);
-template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, int, int, bool, int, hipStream_t, bool);
+template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, const GtopEvalPlan &, bool, hipStream_t);
+template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, const GtopEvalPlan &, bool, hipStream_t);
 
 // ---------------------------------------------------------------------------
 // fp64 -> fp32 copy of the distance field for the GTOP_F32 path

@@ -342,11 +342,13 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
 
 /* ---- tuning knobs (not in the reference) ---------------------------- */
 
-/* Launch geometry of the evaluation kernel: wavefronts per workgroup (1..8)
- * and samples per lane (a divisor of 30: a wavefront then holds 2, 4, 6, 10,
- * 12, 21, 32 or 64 segments, and a workgroup as many whole trajectories as
- * fit).  0 = choose from B and m.  Results do not depend on it beyond fp
- * summation order. */
+/* Launch geometry of the evaluation kernel.  A workgroup is always one
+ * wavefront holding whole trajectories (waves: 0 or 1); samples per lane: 3
+ * (ten lanes per polynomial segment: one trajectory of up to 6 segments per
+ * wavefront), 6 (five lanes per segment: one trajectory of up to 12 segments
+ * at a time, or two of up to 6), 0 = choose from B, m and dtype.  Other values,
+ * and 3 with more than 6 segments, are GTOP_ERR_INVALID (at the call, resp. at
+ * the evaluation).  Results do not depend on it beyond fp summation order. */
 int gtop_set_launch_geometry(gtop_ctx *ctx, int waves, int samples_per_lane);
 /* Batched optimizer: 2 (default) = one launch runs the whole loop (evaluate,
  * MMA update, evaluate, ... max_evals times) for every trajectory — they are

@@ -66,13 +66,13 @@ def test_closed_forms_stated_in_the_derivation(ana):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["A", "B", "C"])
 def test_hip_path_reproduces_the_hand_derived_answers(gtop, ana, case):
-    """Through every body that serves m <= 6 at fp64: the three-wavefront one (auto at B = 1), the barrier-free
-    wavefront kernel (spl 3) and the two-trajectory body (spl 6), in batches of identical rows."""
+    """Through every body that serves m <= 6 at fp64: ten lanes per segment (auto at B = 1, latency variant; spl 3
+    pinned) and five lanes per segment with two trajectories per wavefront (spl 6), in batches of identical rows."""
     ctx = gtop.GtopContext(device=0)
     ctx.set_sdf(field_for(ana, case), ana["grid"], ana["origin"], float(ana["resolution"]))
     ctx.set_params(**params_of(ana, case))
     T, Df, x = ana[f"{case}_T"], ana[f"{case}_Df"], ana[f"{case}_x"]
-    for spl, B in ((0, 1), (3, 7), (6, 7), (1, 2)):
+    for spl, B in ((0, 1), (3, 7), (6, 7), (6, 2)):
         ctx.set_launch_geometry(0, spl)
         ctx.set_problem(np.repeat(T[None], B, 0), np.repeat(Df[None], B, 0))
         c, g = ctx.eval_batch(np.repeat(x[None], B, 0))

@@ -221,12 +221,12 @@ def test_dyn_feasibility_flag(scene, oracle_mod):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("spl,B", [(1, 23), (3, 23), (3, 600), (6, 23), (6, 600), (6, 9000), (15, 23), (0, 9000)])
+@pytest.mark.parametrize("spl,B", [(0, 1), (3, 23), (3, 600), (3, 3101), (6, 23), (6, 600), (6, 9000), (0, 9000)])
 def test_dyn_feasibility_every_body(scene, oracle_mod, dtype, spl, B):
-    """enable_dyn through every compiled body (grad_traj_optimizer.cpp:383-407, :517-535):
-    the three-wavefront SPL = 1 body, the straight-line one-trajectory bodies (SPL 3, 6), the
-    two-trajectories-per-wavefront body (SPL 6 from 8192 / 4096 rows), a rolled generic body
-    (SPL 15), in fp64 and packed fp32, with partial last workgroups (odd B)."""
+    """enable_dyn through every compiled DYN body (grad_traj_optimizer.cpp:383-407, :517-535): ten lanes per segment
+    (one trajectory per wavefront), five lanes per segment with two trajectories per wavefront, in fp64 and fp32
+    (packed pairs at five lanes), with partial last pairs and padding workgroups (odd B).  (7 .. 12 and more than
+    12 segments: tests/test_gpu_kino.py::test_kino_rows_dyn_feasibility.)"""
     import torch
     mp, ctx, sdf = scene
     td = torch.float64 if dtype == "f64" else torch.float32

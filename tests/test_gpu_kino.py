@@ -75,26 +75,33 @@ def test_kino_rows_every_wave_instantiation(scene, oracle_mod, dtype, spl, m, B)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("waves,spl,m,B", [(0, 1, 6, 23), (0, 1, 13, 23), (0, 15, 6, 200), (0, 5, 6, 200), (2, 3, 9, 600),
-                                           (0, 0, 13, 300), (0, 0, 20, 5000), (0, 0, 6, 1), (0, 0, 9, 100)])
+@pytest.mark.parametrize("waves,spl,m,B", [(0, 6, 3, 23), (0, 6, 4, 200), (1, 6, 13, 23), (0, 0, 13, 300), (0, 0, 20, 5000),
+                                           (0, 0, 30, 64), (0, 0, 6, 1), (0, 0, 9, 100), (0, 0, 12, 4100)])
 def test_kino_rows_other_geometries(scene, oracle_mod, dtype, waves, spl, m, B):
-    """Samples-per-lane 1 (a trajectory over several wavefronts), 5 and 15 (several trajectories per wavefront),
-    two-wavefront workgroups, trajectories past 12 segments, and what the auto rule picks for them."""
+    """Two short trajectories per wavefront, trajectories past 12 segments (walked 12 segments at a time), and what
+    the auto rule picks at the batch sizes where it changes its mind."""
     mp, ctx, sdf = scene
     b = _kino(B, m, mp, 1700 + 7 * m + spl)
     c, g = _run(ctx, b, waves, spl, dtype)
     _check(oracle_mod, sdf, b, c, g, TOL64 if dtype == "f64" else TOL32)
 
 
-@pytest.mark.parametrize("spl,m,B", [(0, 6, 37), (1, 6, 23), (3, 6, 600), (6, 6, 600), (6, 12, 200), (0, 13, 64), (0, 6, 9000)])
+@pytest.mark.parametrize("spl,m,B", [(0, 6, 37), (3, 6, 600), (3, 4, 3200), (6, 6, 600), (6, 12, 200), (0, 13, 64), (0, 27, 40),
+                                     (0, 6, 9000)])
 def test_kino_rows_dyn_feasibility(scene, oracle_mod, spl, m, B):
     """enable_dyn (the block commented out at grad_traj_optimizer.cpp:383-407) with such rows: the boundary
-    velocities and accelerations enter its |v|, |a| penalties directly."""
+    velocities and accelerations enter its |v|, |a| penalties directly.  Every DYN body: ten and five lanes per
+    segment, two trajectories per wavefront, 7 .. 12 and more than 12 segments."""
     mp, ctx, sdf = scene
     b = _kino(B, m, mp, 1800 + m + spl)
     p = dict(enable_dyn=1, alpha_v=2.0, r_v=4.0, alpha_a=1.5, r_a=15.0, step=2)
     c, g = _run(ctx, b, 0, spl, "f64", **p)
     _check(oracle_mod, sdf, b, c, g, TOL64, **p)
+    if m <= 12 and B <= 600:          # the fp32 DYN bodies on rows of at least 0.25 s per segment (see test_gpu_api)
+        keep = np.flatnonzero(b.T.min(axis=1) >= 0.25)
+        bb = problem.permute(b, keep)
+        c, g = _run(ctx, bb, 0, spl, "f32", **p)
+        _check(oracle_mod, sdf, bb, c, g, TOL32, **p)
 
 
 @pytest.mark.parametrize("kw", [dict(wc=0.0), dict(step=1), dict(ws=20.0, wc=1.0)])

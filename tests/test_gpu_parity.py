@@ -94,22 +94,42 @@ def test_fp64_parity_host_api(scene, oracle_mod, m, kw):
     assert rc <= TOL64 and rg <= TOL64, (rc, rg)
 
 
-@pytest.mark.parametrize("m", [2, 6, 12, 13])
-@pytest.mark.parametrize("spl", [1, 2, 3, 5, 6, 10, 15, 30])
-@pytest.mark.parametrize("waves", [0, 1, 4])
-def test_fp64_parity_every_launch_geometry(scene, oracle_mod, m, spl, waves):
-    """Samples per lane / waves per block only change the work split."""
+@pytest.mark.parametrize("m", [2, 3, 4, 5, 6, 7, 12, 13, 24, 25, 37])
+@pytest.mark.parametrize("spl", [0, 3, 6])
+@pytest.mark.parametrize("waves", [0, 1])
+def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, waves):
+    """Samples per lane (ten or five lanes per segment, one or two trajectories per wavefront, chunks of 12 segments
+    past 12) only changes the work split.  Ten lanes per segment hold up to 6 segments: refused beyond."""
     mp, ctx, sdf = scene
-    b = problem.make_trajectories(23, m, mp, seed=200 + m)   # odd: exercises a partial last workgroup
+    b = problem.make_trajectories(23, m, mp, seed=200 + m,    # odd: exercises a partial last pair / padding workgroups
+                                  step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0))
     kw = dict(ws=0.0)          # collision term alone: the part the geometry touches
     ctx.set_launch_geometry(waves, spl)
     ctx.set_params(**kw)
     ctx.set_problem(b.T, b.Df)
-    c, g = ctx.eval_batch(b.x)
-    ctx.set_launch_geometry(0, 0)
+    try:
+        if spl == 3 and m > 6:
+            with pytest.raises(gtop.GtopError) as e:
+                ctx.eval_batch(b.x)
+            assert e.value.code == 1
+            return
+        c, g = ctx.eval_batch(b.x)
+    finally:
+        ctx.set_launch_geometry(0, 0)
     c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params(**kw))
     rc, rg = rel_err(c, g, c_ref, g_ref)
     assert rc <= TOL64 and rg <= TOL64, (rc, rg)
+
+
+def test_launch_geometry_values(gtop):
+    """One kernel family: a workgroup is one wavefront; samples per lane 0, 3 or 6."""
+    ctx = gtop.GtopContext(device=0)
+    for waves, spl in ((0, 0), (1, 3), (1, 6), (0, 6)):
+        ctx.set_launch_geometry(waves, spl)
+    for waves, spl in ((2, 3), (4, 0), (0, 1), (0, 5), (0, 15), (0, 30), (-1, 0)):
+        with pytest.raises(gtop.GtopError) as e:
+            ctx.set_launch_geometry(waves, spl)
+        assert e.value.code == 1
 
 
 def test_parity_wide_index_field(gtop, oracle_mod):
@@ -150,12 +170,18 @@ def test_parity_wide_index_field(gtop, oracle_mod):
         assert rc <= 2e-3 and rg <= 2e-3, (spl, rc, rg)
 
 
-@pytest.mark.parametrize("m", [40, 90])
-def test_fp64_parity_long_trajectories(scene, oracle_mod, m):
-    """Many segments: several sample passes per wavefront, up to 8 wavefronts per workgroup and
-    (m = 90) more than 64 KB of LDS per workgroup (opt-in dynamic LDS)."""
+@pytest.mark.parametrize("m", [40, 90, 200])
+def test_fp64_parity_long_trajectories(scene, oracle_mod, gtop, m):
+    """Many segments: the wavefront walks them 12 at a time; m = 90 takes more than 64 KB of LDS per workgroup (opt-in
+    dynamic LDS), m = 200 nearly all 160 KB; past that the request is refused."""
     mp, ctx, sdf = scene
     b = problem.make_trajectories(5, m, mp, seed=4000 + m, step_len=(0.3, 0.8))
+    if m == 200:
+        too_long = problem.make_trajectories(2, 240, mp, seed=4001, step_len=(0.3, 0.8))
+        ctx.set_problem(too_long.T, too_long.Df)
+        with pytest.raises(gtop.GtopError) as e:
+            ctx.eval_batch(too_long.x)
+        assert e.value.code == 1
     ctx.set_launch_geometry(0, 0)
     ctx.set_params()
     ctx.set_problem(b.T, b.Df)

