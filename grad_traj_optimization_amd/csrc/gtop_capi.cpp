@@ -172,6 +172,13 @@ void fill_args(const gtop_ctx *c, GtopKernelArgs<R> &a) {
     a.origin[i] = (R)g.origin[i];
     a.lo[i] = (R)g.min_range[i] + (R)1e-4;   // sdf_map.cpp:56-57
     a.hi[i] = (R)g.max_range[i] - (R)1e-4;   // sdf_map.cpp:62-63
+    // the same bounds for positions that are float values (the reference keeps pos in `float` locals): the smallest
+    // float >= lo and the largest <= hi decide `p < lo` / `p > hi` exactly for every float p
+    float lf = (float)a.lo[i], hf = (float)a.hi[i];
+    if ((double)lf < (double)a.lo[i]) lf = std::nextafterf(lf, INFINITY);
+    if ((double)hf > (double)a.hi[i]) hf = std::nextafterf(hf, -INFINITY);
+    a.lo_f[i] = lf;
+    a.hi_f[i] = hf;
   }
   a.res = (R)g.res;
   a.res_inv = (R)g.res_inv;

@@ -24,6 +24,7 @@ struct GtopKernelArgs {
   int nx, ny, nz;
   R origin[3];
   R lo[3], hi[3];   // min_range + 1e-4, max_range - 1e-4  (isInMap, sdf_map.cpp:55-69)
+  float lo_f[3], hi_f[3];   // lo rounded up / hi rounded down to float: for a float p, p < lo <=> p < lo_f, p > hi <=> p > hi_f
   R res, res_inv;
   // parameters — grad_traj_optimizer.cpp:5-32
   R ws, wc, alpha, d0, alpha_v, r_v, v0, alpha_a, r_a, a0;

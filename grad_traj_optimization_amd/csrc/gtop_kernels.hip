@@ -114,9 +114,13 @@ template <typename R> constexpr bool kIsF32 = false;
 template <> constexpr bool kIsF32<float> = true;
 
 // exp for the per-sample penalty (src/grad_traj_optimizer.cpp:509,:514): one
-// range reduction x = k ln2 + r, |r| <= ln2/2, a degree-11 Taylor/Horner
-// polynomial (truncation 6e-15 relative) and ldexp — about a third of the
-// instructions of the library routine.  |x| beyond the fp64 exponent range
+// range reduction x = k ln2 + r, |r| <= ln2/2, a degree-9 polynomial in Horner
+// form and ldexp — about a third of the instructions of the library routine.
+// The polynomial is 1 + r + r^2/2 + r^3 q(r) with q the degree-6 minimax fit
+// (relative error of the whole: 2.7e-14 on the interval, Lawson iteration in
+// 50-digit arithmetic, checked against exp in double Horner evaluation; the
+// degree-11 Taylor polynomial it replaces: 6e-15, four instructions more per
+// sample) — the three low coefficients stay the inline operands 0.5, 1, 1.  |x| beyond the fp64 exponent range
 // saturates to 0 / inf through v_cvt_i32_f64 (saturating) and v_ldexp_f64;
 // NaN propagates through p.
 // The constants live in a struct so that the latency variant can pin them
@@ -124,19 +128,18 @@ template <> constexpr bool kIsF32<float> = true;
 // otherwise spills to VGPR lanes and re-materialises with s_mov pairs.
 struct ExpConsts {
   double inv_ln2 = 1.4426950408889634074, ln2_hi = -6.93147180369123816490e-01, ln2_lo = -1.90821492927058770002e-10;
-  double c[9] = {2.505210838544172e-08,    // 1/11!
-                 2.755731922398589e-07,    // 1/10!
-                 2.7557319223985893e-06,   // 1/9!
-                 2.48015873015873e-05,     // 1/8!
-                 1.984126984126984e-04,    // 1/7!
-                 1.388888888888889e-03,    // 1/6!
-                 8.333333333333333e-03,    // 1/5!
-                 4.1666666666666664e-02,   // 1/4!
-                 1.6666666666666666e-01};  // 1/3!
+  static constexpr int kN = 7;
+  double c[kN] = {2.7452117538893314e-06,    // r^9  (1/9!  = 2.7557e-06)
+                  2.4872720083484436e-05,    // r^8  (1/8!  = 2.4802e-05)
+                  1.9841623829444966e-04,    // r^7
+                  1.3888830888367963e-03,    // r^6
+                  8.3333330482387603e-03,    // r^5
+                  4.1666666813179924e-02,    // r^4
+                  1.6666666667306995e-01};   // r^3
   __device__ __forceinline__ void pin() {
     asm volatile("" : "+v"(inv_ln2), "+v"(ln2_hi), "+v"(ln2_lo));
 #pragma unroll
-    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(c[i]));
+    for (int i = 0; i < kN; ++i) asm volatile("" : "+v"(c[i]));
   }
 };
 __device__ __forceinline__ double penalty_exp(double x, const ExpConsts &K) {
@@ -145,7 +148,7 @@ __device__ __forceinline__ double penalty_exp(double x, const ExpConsts &K) {
   r = fma(k, K.ln2_lo, r);
   double p = K.c[0];
 #pragma unroll
-  for (int i = 1; i < 9; ++i) p = fma(p, r, K.c[i]);
+  for (int i = 1; i < ExpConsts::kN; ++i) p = fma(p, r, K.c[i]);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
@@ -255,8 +258,15 @@ __device__ __forceinline__ int corner_loads(const GtopKernelArgs<R> &a, int ix, 
 template <typename R> struct SdfTap {
   Pair<R> p00, p01, p10, p11;   // (D[x][y][zb], D[x][y][zb+1]) for the four (x,y) corners
   R dx, dy, dze;                // interpolation weights (dz already folded with the z-border clamp)
-  bool out, zflat;              // outside the map; clamped at a z border (zero z-gradient)
+  bool zflat;                   // clamped at a z border (zero z-gradient)
 };
+
+// isInMap (sdf_map.cpp:55-69) of one position, exactly as the reference tests it
+template <typename R>
+__device__ __forceinline__ bool out_of_map(const R (&lo)[3], const R (&hi)[3], R px, R py, R pz) {
+  return (px < lo[0]) | (py < lo[1]) | (pz < lo[2]) | (px > hi[0]) | (py > hi[1]) | (pz > hi[2]);
+}
+
 
 // isInMap's box (sdf_map.cpp:55-69, margins included) and posToIndex's constants
 template <typename R> struct MapBox {
@@ -267,8 +277,6 @@ template <typename R> struct MapBox {
 template <typename R, bool WIDE>
 __device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, const MapBox<R> &box, R px, R py, R pz) {
   SdfTap<R> tp;
-  tp.out = (px < box.lo[0]) | (py < box.lo[1]) | (pz < box.lo[2]) |
-           (px > box.hi[0]) | (py > box.hi[1]) | (pz > box.hi[2]);
   const R rinv = box.rinv, half = box.half;
   // posToIndex(pos - 0.5 res)  (:201-204 -> :71-74)
   const R tx = (px - half) - box.org[0], ty = (py - half) - box.org[1], tz = (pz - half) - box.org[2];
@@ -319,8 +327,6 @@ __device__ __forceinline__ SdfTap<double> sdf_issue_asm(const GtopKernelArgs<dou
                                                         double px, double py, double pz, gtop_d2 (&raw)[4]) {
   typedef double R;
   SdfTap<R> tp;
-  tp.out = (px < box.lo[0]) | (py < box.lo[1]) | (pz < box.lo[2]) |
-           (px > box.hi[0]) | (py > box.hi[1]) | (pz > box.hi[2]);
   const R rinv = box.rinv, half = box.half;
   const R tx = (px - half) - box.org[0], ty = (py - half) - box.org[1], tz = (pz - half) - box.org[2];
   const R ux = tx * rinv, uy = ty * rinv, uz = tz * rinv;
@@ -353,7 +359,7 @@ __device__ __forceinline__ SdfTap<double> sdf_issue_asm(const GtopKernelArgs<dou
 // comes back UNSCALED — in distance per voxel; the caller folds 1/resolution
 // (:231-239) into the weight that multiplies it.
 template <typename R>
-__device__ __forceinline__ R sdf_blend(const SdfTap<R> &tp, R &gx, R &gy, R &gz, bool &is_out) {
+__device__ __forceinline__ R sdf_blend(const SdfTap<R> &tp, R &gx, R &gy, R &gz) {
   const R dx = tp.dx, dy = tp.dy, dze = tp.dze;
   // values[x][y][z]
   const R v000 = tp.p00.x, v001 = tp.p00.y, v010 = tp.p01.x, v011 = tp.p01.y;
@@ -369,8 +375,7 @@ __device__ __forceinline__ R sdf_blend(const SdfTap<R> &tp, R &gx, R &gy, R &gz,
   const R h0 = gfma(dy, d10 - d00, d00), h1 = gfma(dy, d11 - d01, d01);
   gx = gfma(dze, h1 - h0, h0);                                     // :234-239
   gz = tp.zflat ? (R)0 : dd;
-  is_out = tp.out;
-  return tp.out ? (R)-1 : dist;   // the caller zeroes the gradient's weight when out (grad := 0)
+  return dist;   // (out of the map: the caller overrides value and gradient, sdf_map.cpp:187)
 }
 
 // sum of N consecutive values as a balanced tree (depth log2 N instead of an
@@ -863,14 +868,22 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // sample COUNT depends on the accumulated value) replay the reference's addition chain.
     const bool tiny_T = T < (R)0.0301;
     const bool any_tiny = __ballot(tiny_T) != 0ull;   // wave-uniform, rare
+    // The quotient proper (:351) is only needed on that replay path; the empty asm keeps the dozen instructions of
+    // the division inside the rare branch (the compiler otherwise computes it up front for everybody).
+    auto tiny_dt = [&]() {
+      R Tq = T;
+      asm volatile("" : "+v"(Tq));
+      return Tq / (R)30.0;
+    };
+    const R aw_all = pen_alpha * wdt;
     // (sdt: the sample's own dt, zero past the loop bound — the factor every DYN term carries; unused otherwise)
     auto sample_time = [&](int j, R &t, R &awj, R &sdt) {
       t = (R)(li + j * LPS) * dt + (R)1e-3;
-      awj = pen_alpha * wdt;
+      awj = aw_all;
       sdt = dt;
       if (any_tiny) {
         if (tiny_T) {
-          const R dtq = T / (R)30.0;   // the quotient proper, :351
+          const R dtq = tiny_dt();
           t = (R)1e-3;
           for (int i = 0; i < li + j * LPS; ++i) t += dtq;
           awj = (t < T) ? pen_alpha * (wc * dtq) : (R)0;
@@ -883,7 +896,25 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     [[maybe_unused]] R sdts[NTS];
     if constexpr (MINW <= 2) {
 #pragma unroll
-      for (int j = 0; j < SPL; ++j) sample_time(j, ts[j], aw[j], sdts[j]);
+      for (int j = 0; j < SPL; ++j) {
+        ts[j] = (R)(li + j * LPS) * dt + (R)1e-3;
+        aw[j] = aw_all;
+        sdts[j] = dt;
+      }
+      if (any_tiny) {   // ONE wave-uniform branch for all of the lane's samples: the addition chain runs on from one to the next
+        if (tiny_T) {
+          const R dtq = tiny_dt();
+          R t = (R)1e-3;
+          int i = 0;
+#pragma unroll
+          for (int j = 0; j < SPL; ++j) {
+            for (; i < li + j * LPS; ++i) t += dtq;
+            ts[j] = t;
+            aw[j] = (t < T) ? pen_alpha * (wc * dtq) : (R)0;
+            sdts[j] = (t < T) ? dtq : (R)0;
+          }
+        }
+      }
     }
     // The samples of a lane go through two stages, CH at a time.  Latency regime (MINW = 2): CH = SPL, all 12 corner
     // loads of the lane in flight at once, the jerk term and the speeds computed behind them, the order pinned by
@@ -929,6 +960,15 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       SdfTap<R> taps[CH];
       gtop_d2 raw[ASMLD ? CH : 1][4];
       if constexpr (MINW > 2) sample_time(j0, ts[0], aw[0], sdts[0]);
+      // The position of a sample (:457-465, sums in the reference's order) goes through `float` (the reference's
+      // local), so isInMap's double comparisons (sdf_map.cpp:55-69) are decided exactly by float comparisons against
+      // the bounds rounded INTO the box (a.lo_f = the smallest float >= lo, a.hi_f = the largest <= hi: for a float p,
+      // p < lo <=> p < lo_f).  The common path only asks whether ANY of the lane's CH samples is outside — min / max
+      // over the samples per axis, six compares — and a wave-uniform, rarely taken branch in stage B does the rest.
+      float pmin[3], pmax[3];
+      auto position = [&](int k, R t, R t2, R t3, R t4, R t5) {
+        return (float)(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
+      };
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const R t = ts[MINW <= 2 ? j0 + c : 0];
@@ -938,7 +978,10 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           // :457-465 / :477-485 (sums in the reference's order), then the float round trip
-          pos[k] = round_through_float(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
+          const float pf = position(k, t, t2, t3, t4, t5);
+          pos[k] = (R)pf;
+          pmin[k] = c == 0 ? pf : fminf(pmin[k], pf);
+          pmax[k] = c == 0 ? pf : fmaxf(pmax[k], pf);
           vels[c][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
           if constexpr (DYN)   // getAccelerationFromCoeff, :491-505 (through `float` like the other two)
             accs[c][k] = round_through_float((R)2 * q[k][2] + K.k6 * q[k][3] * t + (R)12 * q[k][4] * t2 + (R)20 * q[k][5] * t3);
@@ -946,6 +989,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         if constexpr (ASMLD) taps[c] = sdf_issue_asm(a, mapbox, pos[0], pos[1], pos[2], raw[c]);
         else taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
       }
+      const bool lane_out = (pmin[0] < a.lo_f[0]) | (pmin[1] < a.lo_f[1]) | (pmin[2] < a.lo_f[2]) |
+                            (pmax[0] > a.hi_f[0]) | (pmax[1] > a.hi_f[1]) | (pmax[2] > a.hi_f[2]);
+      const bool any_out = __ballot(lane_out) != 0ull;   // wave-uniform, rare
       if (j0 == 0) GTOP_STAMP(4);   // corner loads issued
       if constexpr (CH == SPL) GTOP_PHASE_FENCE();   // every corner load is issued above this line ...
       // ... and what does not need them runs while they are in flight: the jerk term and the speeds
@@ -988,14 +1034,21 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
         const R vn = vns[c], ivn = ivns[c];
         R g3[3];
-        bool is_out;
-        const R dist = sdf_blend(taps[c], g3[0], g3[1], g3[2], is_out);   // g3 per voxel, not per metre
+        R dist = sdf_blend(taps[c], g3[0], g3[1], g3[2]);   // g3 per voxel, not per metre
+        if (any_out) {   // (rare) which of the samples it is: the reference's own test on the sample's position
+          const R px = (R)position(0, t, t2, t3, t4, t5), py = (R)position(1, t, t2, t3, t4, t5),
+                  pz = (R)position(2, t, t2, t3, t4, t5);
+          if (out_of_map(mapbox.lo, mapbox.hi, px, py, pz)) {   // dist = -1, grad := 0 (sdf_map.cpp:187)
+            dist = (R)-1;
+            g3[0] = g3[1] = g3[2] = (R)0;
+          }
+        }
         const R e = penalty_exp((pen_d0 - dist) * pen_inv_r, expk);   // exp(-(d - d0)/r)
         const R cdw = aw[MINW <= 2 ? j0 + c : 0] * e;   // wc*dt * cd, cd of :509 (idle lanes: shadow data, never read)
         const R cv = cdw * vn;
         acc[18] = gfma(cdw, vn, acc[18]);   // += cv: :373, weighted as in :417-418 (fusions are spelled out: -ffp-contract=on)
         // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381); gd of :514
-        const R f1 = is_out ? (R)0 : ((pen_gd * a.res_inv) * e) * cv, f2 = cdw * ivn;
+        const R f1 = ((pen_gd * a.res_inv) * e) * cv, f2 = cdw * ivn;   // (out of the map: g3 = 0)
         const R d2 = (R)2 * t, d3 = K.k3 * t2, d4 = (R)4 * t3, d5 = K.k5 * t4;
         [[maybe_unused]] R dw2[3], dw3[3];
         if constexpr (DYN) {
@@ -1115,11 +1168,13 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const R sa = tree_sum<R, LPS>(tile + offA[r]), sb = tree_sum<R, LPS>(tile + offB[r]);
+    R gq = (sa + sb) + K.eps;
+    asm volatile("" : "+v"(gq));   // both reads of the round in front of the store's branch: one LDS round trip, not two
     if (r == kRounds - 1 && cost_lane) csum_seg = sa;
     if constexpr (MMA) {
-      if (okq[r]) gl[lane + 64 * r] = (sa + sb) + K.eps;   // consumed below; nothing leaves the chip
+      if (okq[r]) gl[lane + 64 * r] = gq;   // consumed below; nothing leaves the chip
     } else {
-      if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = (sa + sb) + K.eps;
+      if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = gq;
     }
   }
   // ---- cost (:417-418): every term is already weighted; lanes 48.. hold the segment sums ----
