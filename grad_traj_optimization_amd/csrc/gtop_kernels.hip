@@ -221,13 +221,28 @@ __device__ __forceinline__ float round_through_float(float v) { return v; }
 // WIDE = false (the host checks nx*ny < 2^24, nz < 2^24, field < 4 GiB):
 // 24-bit multiplies (full rate; v_mul_lo_u32 is not) and a uniform base +
 // 32-bit byte offset per lane.  WIDE = true: 64-bit indices, any field.
+// clamp(v, 0, hi) as one v_med3_i32 (the compiler forms med3 only between constants; min(max()) is two instructions,
+// nine times per lane).  Not volatile: free to move and to be eliminated like any arithmetic.  Used by the latency
+// variant's hand-issued lookups only: in the 168-VGPR bodies the asm's operand constraints cost registers the
+// allocator does not have (17 spilled), there the clamp stays min(max()).
+__device__ __forceinline__ int clamp_index_med3(int v, int hi) {
+#ifdef GTOP_NO_MED3
+  return min(max(v, 0), hi);
+#else
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+  return r;
+#endif
+}
+__device__ __forceinline__ int clamp_index(int v, int hi) { return min(max(v, 0), hi); }
+
 template <typename R, bool WIDE>
 __device__ __forceinline__ int corner_loads(const GtopKernelArgs<R> &a, int ix, int iy, int iz,
                                             Pair<R> &p00, Pair<R> &p01, Pair<R> &p10, Pair<R> &p11) {
   const int nx = a.nx, ny = a.ny, nz = a.nz;
-  const int x0 = min(max(ix, 0), nx - 1);
-  const int y0 = min(max(iy, 0), ny - 1);
-  const int zb = min(max(iz, 0), nz - 2);
+  const int x0 = clamp_index(ix, nx - 1);
+  const int y0 = clamp_index(iy, ny - 1);
+  const int zb = clamp_index(iz, nz - 2);
   const bool cx = (unsigned)ix < (unsigned)(nx - 1), cy = (unsigned)iy < (unsigned)(ny - 1);
   if constexpr (!WIDE) {
     const char *D = reinterpret_cast<const char *>(a.sdf);
@@ -336,9 +351,9 @@ __device__ __forceinline__ SdfTap<double> sdf_issue_asm(const GtopKernelArgs<dou
   tp.dy = gfma(ty, rinv, -fy);
   // corner_loads<double, false>, loads by hand
   const int nx = a.nx, ny = a.ny, nz = a.nz;
-  const int x0 = min(max(ix, 0), nx - 1);
-  const int y0 = min(max(iy, 0), ny - 1);
-  const int zb = min(max(iz, 0), nz - 2);
+  const int x0 = clamp_index_med3(ix, nx - 1);
+  const int y0 = clamp_index_med3(iy, ny - 1);
+  const int zb = clamp_index_med3(iz, nz - 2);
   const bool cx = (unsigned)ix < (unsigned)(nx - 1), cy = (unsigned)iy < (unsigned)(ny - 1);
   const uint32_t o00 = (__umul24(__umul24((uint32_t)x0, (uint32_t)ny) + (uint32_t)y0, (uint32_t)nz) + (uint32_t)zb) * 8u;
   const uint32_t sy = cy ? (uint32_t)nz * 8u : 0u;
@@ -404,9 +419,7 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // two SDFMap::getDistWithGradTrilinear queries (src/sdf_map.cpp:185-242)
 template <bool WIDE>
 __device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 px, f2 py, f2 pz,
-                                             f2 &gx, f2 &gy, f2 &gz, bool &outA, bool &outB) {
-  outA = (px.x < a.lo[0]) | (py.x < a.lo[1]) | (pz.x < a.lo[2]) | (px.x > a.hi[0]) | (py.x > a.hi[1]) | (pz.x > a.hi[2]);
-  outB = (px.y < a.lo[0]) | (py.y < a.lo[1]) | (pz.y < a.lo[2]) | (px.y > a.hi[0]) | (py.y > a.hi[1]) | (pz.y > a.hi[2]);
+                                             f2 &gx, f2 &gy, f2 &gz) {
   const f2 res = splat(a.res), rinv = splat(a.res_inv), half = splat(0.5f * a.res);
   const f2 ox = splat(a.origin[0]), oy = splat(a.origin[1]), oz = splat(a.origin[2]);
   f2 fx = ((px - half) - ox) * rinv, fy = ((py - half) - oy) * rinv, fz = ((pz - half) - oz) * rinv;
@@ -474,9 +487,12 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
   const f2 vn = (f2){__builtin_amdgcn_sqrtf(v2.x), __builtin_amdgcn_sqrtf(v2.y)} + splat(1e-5f);   // :358
   const f2 ivn = {__builtin_amdgcn_rcpf(vn.x), __builtin_amdgcn_rcpf(vn.y)};
   f2 g3[3];
-  bool outA, outB;
-  f2 dist = sdf_query_pair<WIDE>(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2], outA, outB);   // :363
-  if (outA) dist.x = -1.0f;   // out of map (sdf_map.cpp:187): dist = -1, grad := 0
+  f2 dist = sdf_query_pair<WIDE>(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2]);   // :363
+  // isInMap (sdf_map.cpp:55-69); out of the map: dist = -1, grad := 0 (sdf_map.cpp:187).  Straight-line
+  // selects: with three wavefronts per SIMD they are cheaper than a rarely taken branch (measured: 21.9 against 22.9 us)
+  const bool outA = out_of_map(a.lo, a.hi, pos[0].x, pos[1].x, pos[2].x);
+  const bool outB = out_of_map(a.lo, a.hi, pos[0].y, pos[1].y, pos[2].y);
+  if (outA) dist.x = -1.0f;
   if (outB) dist.y = -1.0f;
   const f2 arg = (splat(a.d0) - dist) * splat(a.inv_r);
   f2 e = {__expf(arg.x), __expf(arg.y)};          // exp(-(d - d0)/r)
@@ -872,7 +888,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // the division inside the rare branch (the compiler otherwise computes it up front for everybody).
     auto tiny_dt = [&]() {
       R Tq = T;
+#ifndef GTOP_NO_TINY_OPAQUE
       asm volatile("" : "+v"(Tq));
+#endif
       return Tq / (R)30.0;
     };
     const R aw_all = pen_alpha * wdt;
@@ -965,7 +983,11 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       // the bounds rounded INTO the box (a.lo_f = the smallest float >= lo, a.hi_f = the largest <= hi: for a float p,
       // p < lo <=> p < lo_f).  The common path only asks whether ANY of the lane's CH samples is outside — min / max
       // over the samples per axis, six compares — and a wave-uniform, rarely taken branch in stage B does the rest.
-      float pmin[3], pmax[3];
+      // (Only the latency variant: with other wavefronts on the SIMD the straight-line selects are cheaper than the
+      // branch — measured, B = 16 384 fp64: 34.4 us with the selects, 37.6 with the branch.)
+      constexpr bool kRareOut = CH == SPL;
+      [[maybe_unused]] float pmin[3], pmax[3];
+      [[maybe_unused]] bool outs[CH];
       auto position = [&](int k, R t, R t2, R t3, R t4, R t5) {
         return (float)(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
       };
@@ -980,18 +1002,24 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
           // :457-465 / :477-485 (sums in the reference's order), then the float round trip
           const float pf = position(k, t, t2, t3, t4, t5);
           pos[k] = (R)pf;
-          pmin[k] = c == 0 ? pf : fminf(pmin[k], pf);
-          pmax[k] = c == 0 ? pf : fmaxf(pmax[k], pf);
+          if constexpr (kRareOut) {
+            pmin[k] = c == 0 ? pf : fminf(pmin[k], pf);
+            pmax[k] = c == 0 ? pf : fmaxf(pmax[k], pf);
+          }
           vels[c][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
           if constexpr (DYN)   // getAccelerationFromCoeff, :491-505 (through `float` like the other two)
             accs[c][k] = round_through_float((R)2 * q[k][2] + K.k6 * q[k][3] * t + (R)12 * q[k][4] * t2 + (R)20 * q[k][5] * t3);
         }
         if constexpr (ASMLD) taps[c] = sdf_issue_asm(a, mapbox, pos[0], pos[1], pos[2], raw[c]);
         else taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
+        if constexpr (!kRareOut) outs[c] = out_of_map(mapbox.lo, mapbox.hi, pos[0], pos[1], pos[2]);
       }
-      const bool lane_out = (pmin[0] < a.lo_f[0]) | (pmin[1] < a.lo_f[1]) | (pmin[2] < a.lo_f[2]) |
-                            (pmax[0] > a.hi_f[0]) | (pmax[1] > a.hi_f[1]) | (pmax[2] > a.hi_f[2]);
-      const bool any_out = __ballot(lane_out) != 0ull;   // wave-uniform, rare
+      bool any_out = false;
+      if constexpr (kRareOut) {
+        const bool lane_out = (pmin[0] < a.lo_f[0]) | (pmin[1] < a.lo_f[1]) | (pmin[2] < a.lo_f[2]) |
+                              (pmax[0] > a.hi_f[0]) | (pmax[1] > a.hi_f[1]) | (pmax[2] > a.hi_f[2]);
+        any_out = __ballot(lane_out) != 0ull;   // wave-uniform, rare
+      }
       if (j0 == 0) GTOP_STAMP(4);   // corner loads issued
       if constexpr (CH == SPL) GTOP_PHASE_FENCE();   // every corner load is issued above this line ...
       // ... and what does not need them runs while they are in flight: the jerk term and the speeds
@@ -1035,7 +1063,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         const R vn = vns[c], ivn = ivns[c];
         R g3[3];
         R dist = sdf_blend(taps[c], g3[0], g3[1], g3[2]);   // g3 per voxel, not per metre
-        if (any_out) {   // (rare) which of the samples it is: the reference's own test on the sample's position
+        if constexpr (!kRareOut) {   // dist = -1 (sdf_map.cpp:187); grad := 0 below, through its weight f1
+          dist = outs[c] ? (R)-1 : dist;
+        } else if (any_out) {   // (rare) which of the samples it is: the reference's own test on the sample's position
           const R px = (R)position(0, t, t2, t3, t4, t5), py = (R)position(1, t, t2, t3, t4, t5),
                   pz = (R)position(2, t, t2, t3, t4, t5);
           if (out_of_map(mapbox.lo, mapbox.hi, px, py, pz)) {   // dist = -1, grad := 0 (sdf_map.cpp:187)
@@ -1048,7 +1078,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         const R cv = cdw * vn;
         acc[18] = gfma(cdw, vn, acc[18]);   // += cv: :373, weighted as in :417-418 (fusions are spelled out: -ffp-contract=on)
         // g_colli.row(k) += (gd*grad(k)*cd*vn * T*Ldp + cd*(vel(k)/vn) * T*V*Ldp) * dt   (:376-381); gd of :514
-        const R f1 = ((pen_gd * a.res_inv) * e) * cv, f2 = cdw * ivn;   // (out of the map: g3 = 0)
+        R f1 = ((pen_gd * a.res_inv) * e) * cv;   // (out of the map, rare-branch form: g3 = 0)
+        if constexpr (!kRareOut) f1 = outs[c] ? (R)0 : f1;   // grad := 0
+        const R f2 = cdw * ivn;
         const R d2 = (R)2 * t, d3 = K.k3 * t2, d4 = (R)4 * t3, d5 = K.k5 * t4;
         [[maybe_unused]] R dw2[3], dw3[3];
         if constexpr (DYN) {
@@ -1169,7 +1201,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   for (int r = 0; r < kRounds; ++r) {
     const R sa = tree_sum<R, LPS>(tile + offA[r]), sb = tree_sum<R, LPS>(tile + offB[r]);
     R gq = (sa + sb) + K.eps;
+#ifndef GTOP_NO_GQ_PIN
     asm volatile("" : "+v"(gq));   // both reads of the round in front of the store's branch: one LDS round trip, not two
+#endif
     if (r == kRounds - 1 && cost_lane) csum_seg = sa;
     if constexpr (MMA) {
       if (okq[r]) gl[lane + 64 * r] = gq;   // consumed below; nothing leaves the chip
