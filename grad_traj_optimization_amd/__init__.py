@@ -11,7 +11,7 @@ symbol check can run on a CPU box), but creating a context without a gfx950
 device raises.
 """
 from ._lib import (GTOP_F32, GTOP_F64, GtopError, GtopParams, OPTI_NODE_PARAMS,
-                   GtopContext, Rendezvous, library_path, load_library)
+                   GtopContext, GtopGroup, Rendezvous, library_path, load_library)
 
 __all__ = ["GTOP_F32", "GTOP_F64", "GtopError", "GtopParams", "OPTI_NODE_PARAMS",
-           "GtopContext", "Rendezvous", "library_path", "load_library"]
+           "GtopContext", "GtopGroup", "Rendezvous", "library_path", "load_library"]

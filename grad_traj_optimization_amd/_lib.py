@@ -131,6 +131,26 @@ def load_library():
         "gtop_rendezvous_abort": (C.c_int, [vp]),
         "gtop_rendezvous_stats": (C.c_int, [vp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64)]),
         "gtop_set_optimizer_fusion": (C.c_int, [vp, C.c_int]),
+        "gtop_group_create": (C.c_int, [C.POINTER(vp), ip, C.c_int]),
+        "gtop_group_destroy": (C.c_int, [vp]),
+        "gtop_group_size": (C.c_int, [vp]),
+        "gtop_group_context": (vp, [vp, C.c_int]),
+        "gtop_group_last_error": (C.c_char_p, [vp]),
+        "gtop_group_gather_backend": (C.c_char_p, [vp]),
+        "gtop_group_set_params": (C.c_int, [vp, C.POINTER(GtopParams)]),
+        "gtop_group_init_sdf_map": (C.c_int, [vp, dp, dp, C.c_double]),
+        "gtop_group_update_sdf_map": (C.c_int, [vp, dp, C.c_int]),
+        "gtop_group_set_sdf": (C.c_int, [vp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double]),
+        "gtop_group_set_problem": (C.c_int, [vp, C.c_int, C.c_int, dp, C.c_int, dp]),
+        "gtop_group_shard": (C.c_int, [vp, C.c_int, ip, ip]),
+        "gtop_group_eval_batch": (C.c_int, [vp, C.c_int, dp, dp, dp]),
+        "gtop_group_upload_x": (C.c_int, [vp, C.c_int, dp]),
+        "gtop_group_eval_resident": (C.c_int, [vp, C.c_int, C.c_int]),
+        "gtop_group_synchronize": (C.c_int, [vp]),
+        "gtop_group_read_gathered": (C.c_int, [vp, C.c_int, dp, dp]),
+        "gtop_group_device_buffers": (C.c_int, [vp, C.c_int] + [C.POINTER(vp)] * 6),
+        "gtop_group_optimize_batch_ex": (C.c_int, [vp, C.c_int, dp, dp, dp, C.POINTER(GtopStop), dp, C.POINTER(C.c_int32),
+                                                   C.POINTER(C.c_int32)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -524,3 +544,105 @@ class Rendezvous:
             self.close()
         except Exception:
             pass
+
+
+class GtopGroup:
+    """One batch over several devices from one process (include/gtop.h, gtop_group_*): the field replicated, the
+    batch in contiguous slices, every slice launched on its own device, results gathered on the host or all-gathered
+    on the devices (RCCL when the devices differ, peer copies otherwise)."""
+
+    def __init__(self, devices, params=None):
+        self._L = load_library()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._L.gtop_group_create(C.byref(h), devs, len(devices))
+        if rc != 0:
+            raise GtopError(rc, "gtop_group_create: " + self._L.gtop_last_error(None).decode())
+        self._h = h
+        self.devices = [int(d) for d in devices]
+        self.set_params(**(params or {}))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GtopError(rc, self._L.gtop_group_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gtop_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def gather_backend(self):
+        return self._L.gtop_group_gather_backend(self._h).decode()
+
+    def set_params(self, **kw):
+        d = dict(OPTI_NODE_PARAMS)
+        d.update(kw)
+        p = GtopParams(**d)
+        self._chk(self._L.gtop_group_set_params(self._h, C.byref(p)))
+
+    def init_sdf_map(self, map_size, origin, resolution):
+        self._chk(self._L.gtop_group_init_sdf_map(self._h, _p(_f64(map_size)), _p(_f64(origin)), float(resolution)))
+
+    def update_sdf_map(self, pts):
+        pts = _f64(pts).reshape(-1, 3)
+        self._chk(self._L.gtop_group_update_sdf_map(self._h, _p(pts), pts.shape[0]))
+
+    def set_problem(self, T, Df):
+        Df = _f64(Df)
+        B = Df.size // 18
+        T = _f64(T)
+        m, stride = (T.shape[1], T.shape[1]) if T.ndim == 2 else (T.shape[0], 0)
+        self._chk(self._L.gtop_group_set_problem(self._h, B, m, _p(T), stride, _p(Df)))
+        self.B, self.m = B, m
+
+    def shards(self):
+        out = []
+        for i in range(len(self.devices)):
+            a, b = C.c_int(), C.c_int()
+            self._chk(self._L.gtop_group_shard(self._h, i, C.byref(a), C.byref(b)))
+            out.append((a.value, b.value))
+        return out
+
+    def eval_batch(self, x):
+        x = _f64(x)
+        B, n = x.shape
+        cost = np.empty(B)
+        grad = np.empty((B, n))
+        self._chk(self._L.gtop_group_eval_batch(self._h, B, _p(x), _p(cost), _p(grad)))
+        return cost, grad
+
+    def eval_resident(self, x=None, gather=1):
+        """Evaluate the resident slices (x uploaded first when given) and all-gather on the devices; returns, per
+        member, the gathered (cost, grad) as that device holds them (grad None unless gather == 2)."""
+        if x is not None:
+            x = _f64(x)
+            self._chk(self._L.gtop_group_upload_x(self._h, x.shape[0], _p(x)))
+        self._chk(self._L.gtop_group_eval_resident(self._h, int(gather), 1))
+        n = 9 * (self.m - 1)
+        out = []
+        for i in range(len(self.devices)):
+            c = np.empty(self.B)
+            g = np.empty((self.B, n)) if gather == 2 else None
+            self._chk(self._L.gtop_group_read_gathered(self._h, i, _p(c), _p(g) if g is not None else None))
+            out.append((c, g))
+        return out
+
+    def optimize_batch_ex(self, x0, lb, ub, max_evals, ftol_rel=0.0, xtol_rel=0.0, maxtime=0.0):
+        x = _f64(x0).copy()
+        B = x.shape[0]
+        lb, ub = _f64(lb), _f64(ub)
+        cost = np.empty(B)
+        nev = np.empty(B, dtype=np.int32)
+        code = np.empty(B, dtype=np.int32)
+        stop = GtopStop(int(max_evals), float(ftol_rel), float(xtol_rel), float(maxtime))
+        ip = C.POINTER(C.c_int32)
+        self._chk(self._L.gtop_group_optimize_batch_ex(self._h, B, _p(x), _p(lb), _p(ub), C.byref(stop), _p(cost),
+                                                       nev.ctypes.data_as(ip), code.ctypes.data_as(ip)))
+        return x, cost, nev, code

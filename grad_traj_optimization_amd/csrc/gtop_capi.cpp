@@ -823,6 +823,7 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   const bool fused = c->fuse_mma != 0;
   const bool resident = c->fuse_mma == 2;   // one launch runs all max_evals evaluations of every trajectory
   st.iters = resident ? max_evals : 1;
+  st.max_evals = max_evals;
   GtopKernelArgs<double> a;
   fill_args(c, a);
   a.sdf = c->sdf64;

@@ -63,6 +63,12 @@ struct GtopMmaScalars {
   int k, state, nevals;
 };
 
+// NLopt's relstop (stop.c; see mma.hpp)
+__device__ __forceinline__ bool gtop_mma_relstop(double vold, double vnew, double reltol) {
+  if (isinf(vold)) return false;
+  return fabs(vnew - vold) < reltol * (fabs(vnew) + fabs(vold)) * 0.5 || (reltol > 0 && vnew == vold);
+}
+
 __device__ __forceinline__ void gtop_mma_separable_step(int n, int lane, const double *x, const double *dfdx,
                                                         const double *sigma, double rho, const double *lb,
                                                         const double *ub, double *xcur, double *xcur_out, double &g,
@@ -125,15 +131,17 @@ __device__ __forceinline__ void gtop_mma_update_core(const GtopMmaState &st, con
       }
     }
     if (inner_done) {
-      // stop rules, where the host twin has them (mma.hpp:127-137): after the inner loop, on the last
-      // evaluated f against the f the outer iteration started from, and on xcur against xprev
+      // stop rules, where the host twin has them (mma.hpp; NLopt's mma.c): after the inner loop, on the last
+      // evaluated f against the f the outer iteration started from, and on xcur against xprev — x after f, its
+      // verdict standing when both hold — and not at all when this evaluation is the last one allowed: NLopt looks
+      // at the evaluation limit first, so that evaluation reports MAXEVAL (the caller's default for a running state)
       int stop = 0;
       const double fprev = sc.fprev;
-      if (st.ftol_rel > 0 && fabs(fcur - fprev) < st.ftol_rel * (fabs(fcur) + fabs(fprev)) * 0.5) stop = GTOP_MMA_FTOL_REACHED;
-      if (!stop && st.xtol_rel > 0) {
+      const bool at_cap = st.max_evals > 0 && nevals >= st.max_evals;
+      if (!at_cap && gtop_mma_relstop(fprev, fcur, st.ftol_rel)) stop = GTOP_MMA_FTOL_REACHED;
+      if (!at_cap && st.xtol_rel > 0) {
         bool all = true;
-        for (int j = lane; j < n; j += 64)
-          all = all && fabs(v.xcur[j] - v.xprev[j]) < st.xtol_rel * (fabs(v.xcur[j]) + fabs(v.xprev[j])) * 0.5;
+        for (int j = lane; j < n; j += 64) all = all && gtop_mma_relstop(v.xprev[j], v.xcur[j], st.xtol_rel);
         if (__all(all)) stop = GTOP_MMA_XTOL_REACHED;
       }
       if (stop) {

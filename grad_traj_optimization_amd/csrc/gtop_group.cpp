@@ -1,0 +1,456 @@
+// gtop_group.cpp — one batch over several GPUs from ONE host process (include/gtop.h, gtop_group_*).
+//
+// The reference has no multi-device code at all; its path is one NLopt instance per problem calling costFunc serially
+// (src/grad_traj_optimizer.cpp:137-195, :554-562).  The batched callback shards trivially: trajectories
+// are independent, the distance field is read-only.  A group owns one gtop_ctx and one HIP stream per device, keeps
+// the field REPLICATED (built on every device from the same obstacle points), cuts the batch into contiguous slices of
+// ceil(B / n) rows, launches every slice's evaluation on its own device without waiting in between, and collects the
+// results either on the host (gtop_group_eval_batch) or on the devices: an all-gather of the costs (optionally the
+// gradients) so that every device holds the whole batch's results (gtop_group_eval_resident).  There is no reduction
+// anywhere, so results are bit-identical to the unsharded evaluation.
+//
+// The device-side all-gather uses RCCL (ncclAllGather inside a group call, one communicator per device, from
+// librccl.so loaded on first use) when the group's devices are all different, and plain peer copies otherwise (RCCL
+// refuses two ranks on one device; a group may list a device twice, e.g. to overlap two streams on one card or to
+// test on a single-GPU box).  Pure host logic over the public C-ABI: a gtop_ctx is opaque here too.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "gtop.h"
+
+namespace {
+
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool load(std::string &err) {
+    if (lib) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      err = std::string("librccl.so not found: ") + dlerror();
+      return false;
+    }
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString) {
+      err = "librccl.so lacks an expected symbol";
+      return false;
+    }
+    return true;
+  }
+};
+
+struct Member {
+  int device = 0;
+  gtop_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;     // this member's slice (and its outgoing copies) is complete
+  int first = 0, count = 0;      // its slice of the batch
+  double *x = nullptr, *Df = nullptr, *T = nullptr, *cost = nullptr, *grad = nullptr;   // slice buffers, `per` rows
+  double *cost_all = nullptr, *grad_all = nullptr;                                      // gathered: n * per rows
+  double *lb = nullptr, *ub = nullptr;
+  int32_t *nev = nullptr, *code = nullptr;
+  ncclComm_t comm = nullptr;
+};
+
+}  // namespace
+
+struct gtop_group {
+  std::vector<Member> mem;
+  std::string err;
+  int B = 0, m = 0, t_stride = 0, per = 0;   // per = rows per slice (the last may hold fewer)
+  bool have_problem = false, use_rccl = false, x_resident = false;
+  Rccl rccl;
+};
+
+namespace {
+
+int gfail(gtop_group *g, int code, const std::string &msg) {
+  if (g) g->err = msg;
+  return code;
+}
+
+#define GHIP(g, call)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return gfail(g, GTOP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define GCTX(g, mb, call)                                                                     \
+  do {                                                                                        \
+    int rc_ = (call);                                                                         \
+    if (rc_ != GTOP_OK)                                                                       \
+      return gfail(g, rc_, std::string(#call) + " on device " + std::to_string((mb).device) + ": " + gtop_last_error((mb).ctx)); \
+  } while (0)
+
+void free_slices(Member &mb) {
+  (void)hipSetDevice(mb.device);
+  for (void *p : {(void *)mb.x, (void *)mb.Df, (void *)mb.T, (void *)mb.cost, (void *)mb.grad, (void *)mb.cost_all,
+                  (void *)mb.grad_all, (void *)mb.lb, (void *)mb.ub, (void *)mb.nev, (void *)mb.code})
+    if (p) (void)hipFree(p);
+  mb.x = mb.Df = mb.T = mb.cost = mb.grad = mb.cost_all = mb.grad_all = mb.lb = mb.ub = nullptr;
+  mb.nev = mb.code = nullptr;
+}
+
+// results of every slice to every member.  RCCL: one all-gather per member inside a group call (the slices are
+// padded to `per` rows, so the gathered layout [rank][per] IS the batch order).  Copies: each member sends its slice
+// to every member's gathered buffer on its own stream, then every stream waits for every sender.
+int all_gather(gtop_group *g, bool grads) {
+  const int n = (int)g->mem.size();
+  const size_t nvar = 9 * (size_t)(g->m - 1);
+  if (g->use_rccl) {
+    ncclResult_t r = g->rccl.GroupStart();
+    for (int i = 0; i < n && r == ncclSuccess; ++i) {
+      Member &mb = g->mem[i];
+      r = g->rccl.AllGather(mb.cost, mb.cost_all, (size_t)g->per, ncclDouble, mb.comm, mb.stream);
+      if (r == ncclSuccess && grads)
+        r = g->rccl.AllGather(mb.grad, mb.grad_all, (size_t)g->per * nvar, ncclDouble, mb.comm, mb.stream);
+    }
+    const ncclResult_t r2 = g->rccl.GroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess)
+      return gfail(g, GTOP_ERR_HIP, std::string("ncclAllGather: ") + g->rccl.GetErrorString(r != ncclSuccess ? r : r2));
+    return GTOP_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    Member &src = g->mem[i];
+    GHIP(g, hipSetDevice(src.device));
+    for (int j = 0; j < n; ++j) {
+      Member &dst = g->mem[j];
+      GHIP(g, hipMemcpyPeerAsync(dst.cost_all + src.first, dst.device, src.cost, src.device,
+                                 (size_t)src.count * sizeof(double), src.stream));
+      if (grads)
+        GHIP(g, hipMemcpyPeerAsync(dst.grad_all + (size_t)src.first * nvar, dst.device, src.grad, src.device,
+                                   (size_t)src.count * nvar * sizeof(double), src.stream));
+    }
+    GHIP(g, hipEventRecord(src.done, src.stream));
+  }
+  for (int j = 0; j < n; ++j) {
+    GHIP(g, hipSetDevice(g->mem[j].device));
+    for (int i = 0; i < n; ++i)
+      if (i != j) GHIP(g, hipStreamWaitEvent(g->mem[j].stream, g->mem[i].done, 0));
+  }
+  return GTOP_OK;
+}
+
+int sync_all(gtop_group *g) {
+  for (Member &mb : g->mem) {
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipStreamSynchronize(mb.stream));
+  }
+  return GTOP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gtop_group_create(gtop_group **out, const int *devices, int n_devices) {
+  if (!out) return GTOP_ERR_INVALID;
+  *out = nullptr;
+  if (!devices || n_devices < 1 || n_devices > 64) return GTOP_ERR_INVALID;
+  gtop_group *g = new (std::nothrow) gtop_group();
+  if (!g) return GTOP_ERR_INVALID;
+  g->mem.resize(n_devices);
+  std::set<int> distinct;
+  for (int i = 0; i < n_devices; ++i) {
+    Member &mb = g->mem[i];
+    mb.device = devices[i];
+    distinct.insert(devices[i]);
+    int rc = gtop_create(&mb.ctx, mb.device);
+    if (rc == GTOP_OK && hipSetDevice(mb.device) != hipSuccess) rc = GTOP_ERR_HIP;
+    if (rc == GTOP_OK && hipStreamCreateWithFlags(&mb.stream, hipStreamNonBlocking) != hipSuccess) rc = GTOP_ERR_HIP;
+    if (rc == GTOP_OK && hipEventCreateWithFlags(&mb.done, hipEventDisableTiming) != hipSuccess) rc = GTOP_ERR_HIP;
+    if (rc != GTOP_OK) {
+      gtop_group_destroy(g);
+      (void)hipGetLastError();   // (the runtime's error of the failed call must not surface at somebody's next launch)
+      return rc;
+    }
+  }
+  // peers: every pair of different devices that can reach each other directly (the copy path; RCCL finds its own way)
+  for (int i = 0; i < n_devices; ++i)
+    for (int j = 0; j < n_devices; ++j) {
+      const int a = g->mem[i].device, b = g->mem[j].device;
+      int can = 0;
+      if (a != b && hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+        (void)hipSetDevice(a);
+        (void)hipDeviceEnablePeerAccess(b, 0);   // (already enabled: an error we do not care about)
+        (void)hipGetLastError();
+      }
+    }
+  // RCCL needs one rank per device; a device listed twice keeps the group on peer copies.  GTOP_GROUP_GATHER=copy
+  // (environment) forces the copies, =rccl makes a missing librccl an error instead of a fallback.
+  const char *want = std::getenv("GTOP_GROUP_GATHER");
+  const bool force_copy = want && std::strcmp(want, "copy") == 0, force_rccl = want && std::strcmp(want, "rccl") == 0;
+  if (!force_copy && (int)distinct.size() == n_devices) {
+    std::string why;
+    if (g->rccl.load(why)) {
+      std::vector<ncclComm_t> comms(n_devices);
+      const ncclResult_t r = g->rccl.CommInitAll(comms.data(), n_devices, devices);
+      if (r == ncclSuccess) {
+        for (int i = 0; i < n_devices; ++i) g->mem[i].comm = comms[i];
+        g->use_rccl = true;
+      } else {
+        why = std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(r);
+      }
+    }
+    if (!g->use_rccl && force_rccl) {
+      gtop_group_destroy(g);
+      return GTOP_ERR_HIP;
+    }
+  } else if (force_rccl) {
+    gtop_group_destroy(g);
+    return GTOP_ERR_INVALID;   // a device listed twice cannot have an RCCL communicator
+  }
+  *out = g;
+  return GTOP_OK;
+}
+
+int gtop_group_destroy(gtop_group *g) {
+  if (!g) return GTOP_ERR_INVALID;
+  for (Member &mb : g->mem) {
+    if (!mb.stream) continue;
+    (void)hipSetDevice(mb.device);
+    (void)hipStreamSynchronize(mb.stream);
+  }
+  for (Member &mb : g->mem) {
+    if (!mb.ctx) continue;   // (a member whose creation failed: its device ordinal may not even exist)
+    if (mb.comm && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(mb.comm);
+    free_slices(mb);
+    if (mb.done) (void)hipEventDestroy(mb.done);
+    if (mb.stream) (void)hipStreamDestroy(mb.stream);
+    if (mb.ctx) (void)gtop_destroy(mb.ctx);
+  }
+  delete g;
+  return GTOP_OK;
+}
+
+int gtop_group_size(const gtop_group *g) { return g ? (int)g->mem.size() : 0; }
+gtop_ctx *gtop_group_context(gtop_group *g, int i) {
+  return (g && i >= 0 && i < (int)g->mem.size()) ? g->mem[i].ctx : nullptr;
+}
+const char *gtop_group_last_error(const gtop_group *g) { return g ? g->err.c_str() : "gtop_group is NULL"; }
+const char *gtop_group_gather_backend(const gtop_group *g) { return (g && g->use_rccl) ? "rccl" : "copy"; }
+
+int gtop_group_set_params(gtop_group *g, const gtop_params *p) {
+  if (!g) return GTOP_ERR_INVALID;
+  for (Member &mb : g->mem) GCTX(g, mb, gtop_set_params(mb.ctx, p));
+  return GTOP_OK;
+}
+
+int gtop_group_init_sdf_map(gtop_group *g, const double map_size[3], const double origin[3], double resolution) {
+  if (!g) return GTOP_ERR_INVALID;
+  for (Member &mb : g->mem) GCTX(g, mb, gtop_init_sdf_map(mb.ctx, map_size, origin, resolution));
+  return GTOP_OK;
+}
+
+int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts) {
+  if (!g) return GTOP_ERR_INVALID;
+  for (Member &mb : g->mem) GCTX(g, mb, gtop_update_sdf_map(mb.ctx, pts, npts));   // replicated: built on every device
+  return GTOP_OK;
+}
+
+int gtop_group_set_sdf(gtop_group *g, const double *dist_host, int nx, int ny, int nz, const double origin[3],
+                       const double *map_size, double resolution) {
+  if (!g) return GTOP_ERR_INVALID;
+  for (Member &mb : g->mem) GCTX(g, mb, gtop_set_sdf(mb.ctx, dist_host, nx, ny, nz, origin, map_size, resolution));
+  return GTOP_OK;
+}
+
+int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_time, int time_stride, const double *Df) {
+  if (!g) return GTOP_ERR_INVALID;
+  if (B < 1 || m < 2 || !segment_time || !Df || (time_stride != 0 && time_stride != m))
+    return gfail(g, GTOP_ERR_INVALID, "group set_problem: need B >= 1, m >= 2, time_stride in {0, m}");
+  const int n = (int)g->mem.size();
+  const size_t nvar = 9 * (size_t)(m - 1);
+  const int per = (B + n - 1) / n;
+  g->have_problem = false;
+  g->x_resident = false;
+  for (int i = 0; i < n; ++i) {
+    Member &mb = g->mem[i];
+    free_slices(mb);
+    mb.first = std::min(B, i * per);
+    mb.count = std::min(B, mb.first + per) - mb.first;
+    GHIP(g, hipSetDevice(mb.device));
+    // slices padded to `per` rows (RCCL's all-gather sends equal counts); the padding is never read as a result
+    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.x), (size_t)per * nvar * sizeof(double)));
+    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.Df), (size_t)per * 18 * sizeof(double)));
+    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.T), (size_t)(time_stride ? per * m : m) * sizeof(double)));
+    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.cost), (size_t)per * sizeof(double)));
+    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.grad), (size_t)per * nvar * sizeof(double)));
+    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.cost_all), (size_t)n * per * sizeof(double)));
+    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.grad_all), (size_t)n * per * nvar * sizeof(double)));
+    GHIP(g, hipMemsetAsync(mb.cost, 0, (size_t)per * sizeof(double), mb.stream));
+    GHIP(g, hipMemsetAsync(mb.grad, 0, (size_t)per * nvar * sizeof(double), mb.stream));
+    if (mb.count > 0) {
+      GHIP(g, hipMemcpyAsync(mb.Df, Df + (size_t)mb.first * 18, (size_t)mb.count * 18 * sizeof(double),
+                             hipMemcpyHostToDevice, mb.stream));
+      if (time_stride)
+        GHIP(g, hipMemcpyAsync(mb.T, segment_time + (size_t)mb.first * m, (size_t)mb.count * m * sizeof(double),
+                               hipMemcpyHostToDevice, mb.stream));
+    }
+    if (!time_stride)
+      GHIP(g, hipMemcpyAsync(mb.T, segment_time, (size_t)m * sizeof(double), hipMemcpyHostToDevice, mb.stream));
+  }
+  int rc = sync_all(g);
+  if (rc) return rc;
+  g->B = B; g->m = m; g->t_stride = time_stride; g->per = per;
+  g->have_problem = true;
+  return GTOP_OK;
+}
+
+int gtop_group_shard(const gtop_group *g, int i, int *first, int *count) {
+  if (!g || !g->have_problem || i < 0 || i >= (int)g->mem.size()) return GTOP_ERR_INVALID;
+  if (first) *first = g->mem[i].first;
+  if (count) *count = g->mem[i].count;
+  return GTOP_OK;
+}
+
+// every slice's evaluation enqueued on its own device before any is waited for
+static int launch_slices(gtop_group *g) {
+  for (Member &mb : g->mem) {
+    if (mb.count == 0) continue;
+    GCTX(g, mb, gtop_eval_device(mb.ctx, GTOP_F64, mb.count, g->m, mb.x, mb.Df, mb.T, g->t_stride, mb.cost, mb.grad,
+                                 mb.stream));
+  }
+  return GTOP_OK;
+}
+
+int gtop_group_eval_batch(gtop_group *g, int B, const double *x, double *cost, double *grad) {
+  if (!g) return GTOP_ERR_INVALID;
+  if (!g->have_problem) return gfail(g, GTOP_ERR_STATE, "gtop_group_set_problem has not been called");
+  if (B != g->B || !x || !cost || !grad) return gfail(g, GTOP_ERR_INVALID, "group eval_batch: B must be the problem's batch");
+  const size_t nvar = 9 * (size_t)(g->m - 1);
+  for (Member &mb : g->mem) {
+    if (mb.count == 0) continue;
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipMemcpyAsync(mb.x, x + (size_t)mb.first * nvar, (size_t)mb.count * nvar * sizeof(double),
+                           hipMemcpyHostToDevice, mb.stream));
+  }
+  int rc = launch_slices(g);
+  if (rc) return rc;
+  for (Member &mb : g->mem) {
+    if (mb.count == 0) continue;
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipMemcpyAsync(cost + mb.first, mb.cost, (size_t)mb.count * sizeof(double), hipMemcpyDeviceToHost, mb.stream));
+    GHIP(g, hipMemcpyAsync(grad + (size_t)mb.first * nvar, mb.grad, (size_t)mb.count * nvar * sizeof(double),
+                           hipMemcpyDeviceToHost, mb.stream));
+  }
+  g->x_resident = true;
+  return sync_all(g);
+}
+
+int gtop_group_upload_x(gtop_group *g, int B, const double *x) {
+  if (!g) return GTOP_ERR_INVALID;
+  if (!g->have_problem) return gfail(g, GTOP_ERR_STATE, "gtop_group_set_problem has not been called");
+  if (B != g->B || !x) return gfail(g, GTOP_ERR_INVALID, "group upload_x: B must be the problem's batch");
+  const size_t nvar = 9 * (size_t)(g->m - 1);
+  for (Member &mb : g->mem) {
+    if (mb.count == 0) continue;
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipMemcpyAsync(mb.x, x + (size_t)mb.first * nvar, (size_t)mb.count * nvar * sizeof(double),
+                           hipMemcpyHostToDevice, mb.stream));
+  }
+  g->x_resident = true;
+  return sync_all(g);
+}
+
+int gtop_group_eval_resident(gtop_group *g, int gather, int synchronize) {
+  if (!g) return GTOP_ERR_INVALID;
+  if (!g->have_problem || !g->x_resident) return gfail(g, GTOP_ERR_STATE, "group eval_resident: set the problem and upload x first");
+  if (gather < 0 || gather > 2) return gfail(g, GTOP_ERR_INVALID, "gather: 0 none, 1 costs, 2 costs and gradients");
+  int rc = launch_slices(g);
+  if (rc) return rc;
+  if (gather && (rc = all_gather(g, gather == 2))) return rc;
+  return synchronize ? sync_all(g) : GTOP_OK;
+}
+
+int gtop_group_synchronize(gtop_group *g) { return g ? sync_all(g) : GTOP_ERR_INVALID; }
+
+int gtop_group_read_gathered(gtop_group *g, int member, double *cost, double *grad) {
+  if (!g || !g->have_problem || member < 0 || member >= (int)g->mem.size()) return GTOP_ERR_INVALID;
+  Member &mb = g->mem[member];
+  const size_t nvar = 9 * (size_t)(g->m - 1);
+  GHIP(g, hipSetDevice(mb.device));
+  if (cost) GHIP(g, hipMemcpyAsync(cost, mb.cost_all, (size_t)g->B * sizeof(double), hipMemcpyDeviceToHost, mb.stream));
+  if (grad)
+    GHIP(g, hipMemcpyAsync(grad, mb.grad_all, (size_t)g->B * nvar * sizeof(double), hipMemcpyDeviceToHost, mb.stream));
+  GHIP(g, hipStreamSynchronize(mb.stream));
+  return GTOP_OK;
+}
+
+int gtop_group_device_buffers(gtop_group *g, int member, void **d_x, void **d_cost, void **d_grad, void **d_cost_all,
+                              void **d_grad_all, void **hip_stream) {
+  if (!g || !g->have_problem || member < 0 || member >= (int)g->mem.size()) return GTOP_ERR_INVALID;
+  Member &mb = g->mem[member];
+  if (d_x) *d_x = mb.x;
+  if (d_cost) *d_cost = mb.cost;
+  if (d_grad) *d_grad = mb.grad;
+  if (d_cost_all) *d_cost_all = mb.cost_all;
+  if (d_grad_all) *d_grad_all = mb.grad_all;
+  if (hip_stream) *hip_stream = mb.stream;
+  g->x_resident = true;   // the caller writes x where it lives
+  return GTOP_OK;
+}
+
+int gtop_group_optimize_batch_ex(gtop_group *g, int B, double *x, const double *lb, const double *ub,
+                                 const gtop_stop *stop, double *min_cost, int32_t *nevals, int32_t *code) {
+  if (!g) return GTOP_ERR_INVALID;
+  if (!g->have_problem) return gfail(g, GTOP_ERR_STATE, "gtop_group_set_problem has not been called");
+  if (B != g->B || !x || !lb || !ub || !stop) return gfail(g, GTOP_ERR_INVALID, "group optimize: B must be the problem's batch");
+  const size_t nvar = 9 * (size_t)(g->m - 1);
+  for (Member &mb : g->mem) {
+    if (mb.count == 0) continue;
+    GHIP(g, hipSetDevice(mb.device));
+    const size_t bytes = (size_t)mb.count * nvar * sizeof(double);
+    if (!mb.lb) {
+      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.lb), (size_t)g->per * nvar * sizeof(double)));
+      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.ub), (size_t)g->per * nvar * sizeof(double)));
+      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.nev), (size_t)g->per * sizeof(int32_t)));
+      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.code), (size_t)g->per * sizeof(int32_t)));
+    }
+    GHIP(g, hipMemcpyAsync(mb.x, x + (size_t)mb.first * nvar, bytes, hipMemcpyHostToDevice, mb.stream));
+    GHIP(g, hipMemcpyAsync(mb.lb, lb + (size_t)mb.first * nvar, bytes, hipMemcpyHostToDevice, mb.stream));
+    GHIP(g, hipMemcpyAsync(mb.ub, ub + (size_t)mb.first * nvar, bytes, hipMemcpyHostToDevice, mb.stream));
+  }
+  for (Member &mb : g->mem) {   // every device's whole optimisation is one launch; none waits for another
+    if (mb.count == 0) continue;
+    GCTX(g, mb, gtop_optimize_device_ex(mb.ctx, mb.count, g->m, mb.x, mb.Df, mb.T, g->t_stride, mb.lb, mb.ub, stop,
+                                        mb.cost, mb.nev, mb.code, mb.stream));
+  }
+  for (Member &mb : g->mem) {
+    if (mb.count == 0) continue;
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipMemcpyAsync(x + (size_t)mb.first * nvar, mb.x, (size_t)mb.count * nvar * sizeof(double),
+                           hipMemcpyDeviceToHost, mb.stream));
+    if (min_cost)
+      GHIP(g, hipMemcpyAsync(min_cost + mb.first, mb.cost, (size_t)mb.count * sizeof(double), hipMemcpyDeviceToHost, mb.stream));
+    if (nevals)
+      GHIP(g, hipMemcpyAsync(nevals + mb.first, mb.nev, (size_t)mb.count * sizeof(int32_t), hipMemcpyDeviceToHost, mb.stream));
+    if (code)
+      GHIP(g, hipMemcpyAsync(code + mb.first, mb.code, (size_t)mb.count * sizeof(int32_t), hipMemcpyDeviceToHost, mb.stream));
+  }
+  g->x_resident = true;
+  return sync_all(g);
+}
+
+}  // extern "C"

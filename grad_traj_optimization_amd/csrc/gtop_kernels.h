@@ -41,6 +41,7 @@ struct GtopMmaState {
   int *k, *state, *nevals;                                // [B]; state 0 first evaluation pending, 1 running,
                                                           //      >= 3 stopped with that nlopt_result code
   int iters;                                              // evaluations per launch of the fused kernel
+  int max_evals;                                          // the optimisation's evaluation cap (all launches together)
   // stop rules beside the evaluation count (mma.hpp:35-39; nlopt set_ftol_rel / set_xtol_rel / set_maxtime,
   // grad_traj_optimizer.cpp:144-148); 0 = off.  max_ticks: wall clock in ticks of the 100 MHz device clock.
   double ftol_rel, xtol_rel;

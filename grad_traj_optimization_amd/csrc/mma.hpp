@@ -46,6 +46,12 @@ struct MmaResult {
   int nevals = 0;
 };
 
+// NLopt's relstop (stop.c) without the absolute tolerance the reference never sets
+inline bool mma_relstop(double vold, double vnew, double reltol) {
+  if (std::isinf(vold)) return false;
+  return std::fabs(vnew - vold) < reltol * (std::fabs(vnew) + std::fabs(vold)) * 0.5 || (reltol > 0 && vnew == vold);
+}
+
 // One separable step from base point x with gradient dfdx, asymptote widths
 // sigma and conservativeness rho: fills xcur and returns the approximant's
 // value g(xcur) and w(xcur) = 0.5 * sum dx^2 / (sigma^2 - dx^2).
@@ -125,22 +131,24 @@ inline MmaResult mma_minimize(unsigned n, mma_objective f, void *f_data, const d
         std::memcpy(x, xcur.data(), sizeof(double) * n);
         dfdx = dfdx_cur;
       }
+      // NLopt's order (mma.c): the evaluation and time limits are looked at right after every evaluation, BEFORE the
+      // inner loop may end — an evaluation that is the last one allowed reports MAXEVAL even where it also completes
+      // an outer iteration that meets ftol / xtol
+      if (int s = stop_now()) { ret = s; break; }
       if (inner_done) break;
       if (fcur > gval) rho = std::fmin(10 * rho, 1.1 * (rho + (fcur - gval) / wval));
-      if (int s = stop_now()) { ret = s; break; }
     }
     if (ret != MMA_SUCCESS) break;
 
-    if (opt.ftol_rel > 0 && std::fabs(fcur - fprev) < opt.ftol_rel * (std::fabs(fcur) + std::fabs(fprev)) * 0.5) {
-      ret = MMA_FTOL_REACHED;
-      break;
-    }
+    // nlopt_stop_ftol / nlopt_stop_x (stop.c, relstop): |new - old| < tol * (|new| + |old|) / 2, or new == old with a
+    // tolerance set (catches new == old == 0); x is tested after f and its verdict stands when both hold
+    if (mma_relstop(fprev, fcur, opt.ftol_rel)) ret = MMA_FTOL_REACHED;
     if (opt.xtol_rel > 0) {
       bool all = true;
-      for (unsigned j = 0; j < n && all; ++j)
-        all = std::fabs(xcur[j] - xprev[j]) < opt.xtol_rel * (std::fabs(xcur[j]) + std::fabs(xprev[j])) * 0.5;
-      if (all) { ret = MMA_XTOL_REACHED; break; }
+      for (unsigned j = 0; j < n && all; ++j) all = mma_relstop(xprev[j], xcur[j], opt.xtol_rel);
+      if (all) ret = MMA_XTOL_REACHED;
     }
+    if (ret != MMA_SUCCESS) break;
 
     // asymptote and rho update for outer iteration k+1
     rho = std::fmax(0.1 * rho, kRhoMin);

@@ -211,6 +211,57 @@ int gtop_eval_device(gtop_ctx *ctx, int dtype, int B, int m, const void *d_x,
                      const void *d_Df, const void *d_T, int time_stride,
                      void *d_cost, void *d_grad, void *hip_stream);
 
+/* ---- one batch over several GPUs from one process -------- */
+/* Nothing in the reference is multi-device (one NLopt instance per problem,
+ * src/grad_traj_optimizer.cpp:137-195); the batched callback shards trivially:
+ * trajectories are independent and the field is read-only.  A group owns one
+ * gtop_ctx and one HIP stream per listed device (a device may be listed more
+ * than once), keeps the distance field REPLICATED (gtop_group_init_sdf_map /
+ * _update_sdf_map / _set_sdf build it on every device), and cuts the batch of
+ * gtop_group_set_problem into contiguous slices of ceil(B / n) rows
+ * (gtop_group_shard).  Every slice is launched on its own device before any is
+ * waited for; there is no reduction, so results are bit-identical to the
+ * unsharded evaluation.
+ *   gtop_group_eval_batch        host buffers in and out (fp64), like
+ *                                gtop_eval_batch
+ *   gtop_group_upload_x + gtop_group_eval_resident(gather, synchronize)
+ *                                everything resident; gather = 1 all-gathers
+ *                                the costs, 2 also the gradients, so that EVERY
+ *                                device holds the whole batch's results
+ *                                (gtop_group_read_gathered copies one device's
+ *                                set to the host; gtop_group_device_buffers
+ *                                hands out the device pointers and the stream)
+ *   gtop_group_optimize_batch_ex the batched optimizer, one launch per device
+ * The all-gather is RCCL's (ncclAllGather in a group call, one communicator per
+ * device, librccl.so loaded on first use) when all listed devices differ, peer
+ * copies otherwise — gtop_group_gather_backend says which ("rccl" / "copy");
+ * GTOP_GROUP_GATHER=copy|rccl in the environment at gtop_group_create forces
+ * one.  One host thread at a time per group. */
+typedef struct gtop_group gtop_group;
+int gtop_group_create(gtop_group **out, const int *devices, int n_devices);
+int gtop_group_destroy(gtop_group *g);
+int gtop_group_size(const gtop_group *g);
+gtop_ctx *gtop_group_context(gtop_group *g, int member);
+const char *gtop_group_last_error(const gtop_group *g);
+const char *gtop_group_gather_backend(const gtop_group *g);
+int gtop_group_set_params(gtop_group *g, const gtop_params *p);
+int gtop_group_init_sdf_map(gtop_group *g, const double map_size[3], const double origin[3], double resolution);
+int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts);
+int gtop_group_set_sdf(gtop_group *g, const double *dist_host, int nx, int ny, int nz, const double origin[3],
+                       const double *map_size, double resolution);
+int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_time, int time_stride,
+                           const double *Df);
+int gtop_group_shard(const gtop_group *g, int member, int *first, int *count);
+int gtop_group_eval_batch(gtop_group *g, int B, const double *x, double *cost, double *grad);
+int gtop_group_upload_x(gtop_group *g, int B, const double *x);
+int gtop_group_eval_resident(gtop_group *g, int gather, int synchronize);
+int gtop_group_synchronize(gtop_group *g);
+/* the gathered results as member `member` holds them: cost B, grad B*n host doubles (either may be NULL) */
+int gtop_group_read_gathered(gtop_group *g, int member, double *cost, double *grad);
+/* member's slice buffers (ceil(B/n) rows each), its gathered buffers (n*ceil(B/n) rows) and its hipStream_t */
+int gtop_group_device_buffers(gtop_group *g, int member, void **d_x, void **d_cost, void **d_grad,
+                              void **d_cost_all, void **d_grad_all, void **hip_stream);
+
 /* ---- batched optimizer driver -------------------- */
 
 /* Box bounds of GradTrajOptimizer::optimizeTrajectory
@@ -261,6 +312,9 @@ int gtop_optimize_device_ex(gtop_ctx *ctx, int B, int m, void *d_x, const void *
                             const void *d_T, int time_stride, const void *d_lb,
                             const void *d_ub, const gtop_stop *stop, void *d_min_cost,
                             int32_t *d_nevals, int32_t *d_code, void *hip_stream);
+/* the same over a group's devices (B = the batch of gtop_group_set_problem): one launch per device */
+int gtop_group_optimize_batch_ex(gtop_group *g, int B, double *x, const double *lb, const double *ub,
+                                 const gtop_stop *stop, double *min_cost, int32_t *nevals, int32_t *code);
 
 /* ---- post-processing ------------------------------ */
 

@@ -1,0 +1,98 @@
+"""The multi-device entry of the C-ABI (include/gtop.h, gtop_group_*) on what one card allows: a group
+that lists device 0 several times (peer-copy gather), and a group of one device with an RCCL communicator of size 1.
+Results must be the unsharded evaluation's, bit for bit — sharding has no reduction anywhere.  (N > 1 devices is the
+same code with different ordinals; it has not run on hardware from here — DESIGN §7.)"""
+import numpy as np
+import pytest
+
+from grad_traj_optimization_amd import problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene(gtop):
+    mp = problem.make_map((60, 50, 30), density=0.03, seed=11)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    return mp, ctx
+
+
+def _group(gtop, mp, devices):
+    g = gtop.GtopGroup(devices)
+    g.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    g.update_sdf_map(mp.obstacle_points())
+    return g
+
+
+@pytest.mark.parametrize("members,B,m", [(3, 1000, 6), (4, 23, 6), (2, 4500, 12), (5, 3, 6)])
+def test_slices_on_one_card_equal_the_unsharded_batch(scene, gtop, members, B, m):
+    """n contexts on device 0, peer-copy gather: host-buffer results, the gathered copies every member holds, and
+    the slice bounds (contiguous, ceil(B / n) rows; members past the batch's end hold nothing)."""
+    mp, ctx = scene
+    b = problem.make_trajectories(B, m, mp, seed=40 + members, step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0),
+                                  boundary="random")
+    ctx.set_params()
+    ctx.set_problem(b.T, b.Df)
+    c_ref, g_ref = ctx.eval_batch(b.x)
+    g = _group(gtop, mp, [0] * members)
+    assert g.gather_backend == "copy"
+    g.set_problem(b.T, b.Df)
+    per = -(-B // members)
+    assert g.shards() == [(min(B, i * per), min(B, (i + 1) * per) - min(B, i * per)) for i in range(members)]
+    c, gr = g.eval_batch(b.x)
+    assert np.array_equal(c, c_ref) and np.array_equal(gr, g_ref)
+    for ci, gi in g.eval_resident(gather=2):                        # x is resident from the call above
+        assert np.array_equal(ci, c_ref) and np.array_equal(gi, g_ref)
+    x2 = b.x + 0.01
+    c2_ref, _ = ctx.eval_batch(x2)
+    for ci, gi in g.eval_resident(x2, gather=1):
+        assert np.array_equal(ci, c2_ref) and gi is None
+    g.close()
+
+
+def test_group_of_one_with_an_rccl_communicator(scene, gtop, monkeypatch):
+    """All listed devices differ (there is one): the device-side gather is RCCL's ncclAllGather, communicator of
+    size 1 — the call path N > 1 devices take."""
+    mp, ctx = scene
+    monkeypatch.setenv("GTOP_GROUP_GATHER", "rccl")       # a missing or failing librccl is an error, not a fallback
+    g = _group(gtop, mp, [0])
+    monkeypatch.delenv("GTOP_GROUP_GATHER")
+    assert g.gather_backend == "rccl"
+    b = problem.make_trajectories(777, 6, mp, seed=50)
+    ctx.set_params()
+    ctx.set_problem(b.T, b.Df)
+    c_ref, g_ref = ctx.eval_batch(b.x)
+    g.set_problem(b.T, b.Df)
+    for _ in range(2):
+        (ci, gi), = g.eval_resident(b.x, gather=2)
+        assert np.array_equal(ci, c_ref) and np.array_equal(gi, g_ref)
+    with pytest.raises(gtop.GtopError):
+        monkeypatch.setenv("GTOP_GROUP_GATHER", "rccl")
+        gtop.GtopGroup([0, 0])                            # RCCL wants one rank per device
+    g.close()
+
+
+def test_group_optimizer_and_errors(scene, gtop):
+    mp, ctx = scene
+    B, m = 300, 6
+    b = problem.make_trajectories(B, m, mp, seed=60)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    ctx.set_params()
+    ctx.set_problem(b.T, b.Df)
+    ref = ctx.optimize_batch_ex(b.x, lb, ub, 20, ftol_rel=1e-3)
+    g = _group(gtop, mp, [0, 0, 0])
+    with pytest.raises(gtop.GtopError) as e:
+        g.eval_batch(b.x)                                 # no problem yet
+    assert e.value.code == 4
+    g.set_problem(b.T, b.Df)
+    got = g.optimize_batch_ex(b.x, lb, ub, 20, ftol_rel=1e-3)
+    for a, r in zip(got, ref):
+        assert np.array_equal(a, r)
+    with pytest.raises(gtop.GtopError) as e:
+        g.eval_batch(b.x[:10])                            # the group's batch is fixed by set_problem
+    assert e.value.code == 1
+    with pytest.raises(gtop.GtopError):
+        gtop.GtopGroup([0, 99])                           # no such device
+    g.close()

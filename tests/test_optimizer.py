@@ -46,6 +46,7 @@ def mma_serial(f, x0, lb, ub, max_evals, ftol_rel=0.0, xtol_rel=0.0, full=False)
         return xc, g, w
 
     code = 5
+    capped = False
     while nev < max_evals:
         fprev = fcur
         k += 1
@@ -61,17 +62,23 @@ def mma_serial(f, x0, lb, ub, max_evals, ftol_rel=0.0, xtol_rel=0.0, full=False)
             if fcur < minf:
                 minf, x, dfdx = fcur, xcur.copy(), dcur
             trace.append(minf)
+            if nev >= max_evals:                             # NLopt looks at the evaluation limit first (mma.c)
+                capped = True
+                break
             if inner_done:
                 break
             if fcur > gval:
                 rho = min(10 * rho, 1.1 * (rho + (fcur - gval) / wval))
-        if not inner_done:
-            break                                            # out of evaluations inside the inner loop
-        if ftol_rel > 0 and abs(fcur - fprev) < ftol_rel * (abs(fcur) + abs(fprev)) * 0.5:
-            code = 3
+        if capped:
             break
-        if xtol_rel > 0 and np.all(np.abs(xcur - xprev) < xtol_rel * (np.abs(xcur) + np.abs(xprev)) * 0.5):
-            code = 4
+
+        def relstop(old, new, tol):                          # NLopt's stop.c
+            return (np.abs(new - old) < tol * (np.abs(new) + np.abs(old)) * 0.5) | ((tol > 0) & (new == old))
+        if relstop(fprev, fcur, ftol_rel):
+            code = 3
+        if xtol_rel > 0 and np.all(relstop(xprev, xcur, xtol_rel)):
+            code = 4                                         # x after f: its verdict stands when both hold
+        if code != 5:
             break
         rho = max(0.1 * rho, 1e-5)
         if k > 1:
@@ -332,3 +339,52 @@ def test_whole_optimisation_replays_from_a_hip_graph(scene, gtop):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(xr, x_e) and torch.equal(cr, c_e)
+
+
+def test_stop_rule_precedence_follows_nlopt(scene, oracle_mod, gtop):
+    """The corner cases of NLopt's own stop logic (mma.c / stop.c): xtol is tested after ftol and its verdict stands
+    when both hold (code 4, not 3); the evaluation limit is looked at right after every evaluation, so an evaluation
+    that is the last one allowed reports MAXEVAL (5) even where it also completes an outer iteration meeting ftol.
+    Device (the one-launch loop and the per-iteration launch form) against the numpy twin, on the jerk term alone."""
+    mp, ctx, sdf = scene
+    B, m = 16, 6
+    b = problem.make_trajectories(B, m, mp, seed=710)
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    kw = dict(wc=0.0)
+    prm = oracle_mod.make_params(**kw)
+    ctx.set_problem(b.T, b.Df)
+    ctx.set_params(**kw)
+    try:
+        # (1) both tolerances loose: wherever f AND x pass at the same outer iteration the code is 4
+        rule = dict(ftol_rel=0.3, xtol_rel=0.5)
+        xs, costs, nev, code = ctx.optimize_batch_ex(b.x, lb, ub, 60, **rule)
+        refs = []
+        for i in range(B):
+            gen = oracle_mod.generator(b.T[i])
+
+            def f(x, i=i, gen=gen):
+                return oracle_mod.cost_grad(b.T[i], b.Df[i], x, sdf, prm, L=gen["L"], R=gen["R"])
+            refs.append(mma_serial(f, b.x[i], lb[i], ub[i], 60, full=True, **rule))
+            assert (nev[i], code[i]) == (refs[i][3], refs[i][4]), (i, nev[i], code[i], refs[i][3:])
+        assert (code == 4).any() and set(code.tolist()) <= {3, 4}
+        # (2) the cap placed exactly on the evaluation at which ftol fires: MAXEVAL wins
+        rule = dict(ftol_rel=5e-2)
+        _, _, nev_free, code_free = ctx.optimize_batch_ex(b.x, lb, ub, 80, **rule)
+        assert (code_free == 3).sum() >= B // 2
+        cap = int(np.bincount(nev_free[code_free == 3]).argmax())        # the most common stopping evaluation
+        for mode in (2, 1):
+            ctx.set_optimizer_fusion(mode)
+            _, _, nev_c, code_c = ctx.optimize_batch_ex(b.x, lb, ub, cap, **rule)
+            hit = (nev_free == cap) & (code_free == 3)
+            assert hit.any() and (code_c[hit] == 5).all() and (nev_c[hit] == cap).all()
+            early = (nev_free < cap) & (code_free == 3)
+            assert (code_c[early] == 3).all() and np.array_equal(nev_c[early], nev_free[early])
+        for i in np.flatnonzero(hit)[:3]:
+            gen = oracle_mod.generator(b.T[i])
+
+            def f(x, i=i, gen=gen):
+                return oracle_mod.cost_grad(b.T[i], b.Df[i], x, sdf, prm, L=gen["L"], R=gen["R"])
+            assert mma_serial(f, b.x[i], lb[i], ub[i], cap, full=True, **rule)[3:] == (cap, 5)
+    finally:
+        ctx.set_optimizer_fusion(2)
+        ctx.set_params()
