@@ -77,17 +77,25 @@ edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, c
       idx[k] = (int)floor((pm - g.origin[k]) * g.res_inv);
       diff[k] = (p[k] - ((idx[k] + 0.5) * g.res + g.origin[k])) * g.res_inv;
     }
+    // The 8 corner loads of sdf_map.cpp:211-219, each index clamped per axis (getDistance(int,int,int), :166-174), as
+    // FOUR 16-byte loads: z is the fastest axis, so the two z-corners of an (x,y) column are neighbours — the pair
+    // (D[zb], D[zb+1]) with zb = clamp(iz, 0, nz-2) holds both, and at a z border, where both corners clamp to the
+    // same voxel, that voxel is the pair's first (iz < 0) or second (iz > nz-2) element.  Same values, half the
+    // requests (the lookup of the cost/gradient kernel, gtop_kernels.hip corner_loads, does the same).
+    {
+      struct __attribute__((packed, aligned(8))) Pair { double lo, hi; };
+      const int zb = min(max(idx[2], 0), g.nz - 2);
+      const bool z_low = idx[2] < 0, z_high = idx[2] > g.nz - 2;
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+      for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int z = 0; z < 2; ++z) {
-          // getDistance(int,int,int): per-axis clamp, sdf_map.cpp:176-183
-          const int cx = min(max(idx[0] + x, 0), g.nx - 1), cy = min(max(idx[1] + y, 0), g.ny - 1),
-                    cz = min(max(idx[2] + z, 0), g.nz - 1);
-          values[x][y][z] = field[((size_t)cx * g.ny + cy) * g.nz + cz];
+        for (int y = 0; y < 2; ++y) {
+          const int cx = min(max(idx[0] + x, 0), g.nx - 1), cy = min(max(idx[1] + y, 0), g.ny - 1);
+          const Pair pr = *reinterpret_cast<const Pair *>(field + ((size_t)cx * g.ny + cy) * g.nz + zb);
+          values[x][y][0] = z_high ? pr.hi : pr.lo;
+          values[x][y][1] = z_low ? pr.lo : pr.hi;
         }
+    }
   }
   // min over the boxes (edt_environment.cpp:26-73): at the 8 corner centres (:96-98), or at the position (:131)
   double dbox = 10000000.0;   // :64
