@@ -59,3 +59,20 @@ def test_product_does_not_touch_the_oracle():
                 assert "gtop_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
     out = os.popen(f"ldd {os.path.join(pkg, 'libgtop_hip.so')}").read()
     assert "oracle" not in out
+
+
+def test_no_kernel_spills_to_scratch_memory():
+    """Build-time check (hipcc -Rpass-analysis=kernel-resource-usage, tools/kernel_resources.py): no instantiation of
+    the evaluation kernel uses scratch memory.  The latency variant issues its distance-field loads through inline asm
+    whose outstanding results the compiler cannot see; that is only sound while the register allocator keeps them
+    where they land, i.e. while nothing spills — a compiler or flag change that breaks it fails here, not silently."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows, _ = kr.analyse(asm_out=os.path.join(ROOT, "grad_traj_optimization_amd", "csrc", "_obj", "resources.s"))
+    assert len(rows) >= 60
+    bad = [r for r in rows if r["scratch"] or r["vgpr_spill"]]
+    assert not bad, bad
+    hot = [r for r in rows if r["kernel"].startswith("gtop_eval_wave_kernel<double, false, 3, 1, true, 2, GtopNoMma")]
+    assert len(hot) == 1 and hot[0]["sgpr_spill"] == 0 and hot[0]["waves_per_simd"] == 2, hot

@@ -102,3 +102,51 @@ def test_rows_do_not_depend_on_their_place(scene):
         if spl == 6:                                   # same body at any batch size
             cs, gs = _run(ctx, problem.permute(b, perm[:11]), spl, dtype)
             assert np.array_equal(cs, c[perm[:11]]) and np.array_equal(gs, g[perm[:11]])
+
+
+@pytest.mark.timeout(900)
+def test_hand_issued_loads_equal_compiler_issued_loads(scene, tmp_path):
+    """The latency variant with its distance-field loads issued by hand (inline asm + hand-written s_waitcnt, the
+    shipped build) against the same variant built with -DGTOP_ASM_LOADS=0 (the compiler's own loads and waits): bit
+    for bit the same results.  The second library is compiled here (hipcc is on the GPU box) and driven in a child
+    process through GTOP_HIP_LIB."""
+    import os
+    import subprocess
+    import sys
+    mp, ctx, sdf = scene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = str(tmp_path / "libgtop_noasm.so")
+    subprocess.check_call(["make", "-C", os.path.join(root, "grad_traj_optimization_amd", "csrc"), "-s", "-j", "8", "lib",
+                           f"OUT={alt}", "EXTRA=-DGTOP_ASM_LOADS=0"], timeout=800)
+    script = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import grad_traj_optimization_amd as gtop
+from grad_traj_optimization_amd import problem
+mp = problem.make_map((60, 50, 30), density=0.03, seed=11)
+ctx = gtop.GtopContext(device=0)
+ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+ctx.update_sdf_map(mp.obstacle_points())
+out = {}
+for B, m in ((1, 6), (777, 6), (100, 3)):
+    b = problem.make_trajectories(B, m, mp, seed=31 + B, boundary="random")
+    x = b.x.copy()
+    if B == 777:
+        x[:5, 0] += 30.0                      # out-of-map samples: the rare branch
+    ctx.set_problem(b.T, b.Df)
+    c, g = ctx.eval_batch(x)
+    out[f"c{B}"], out[f"g{B}"] = c, g
+np.savez(sys.argv[1], **out)
+""" % root
+    res = {}
+    for name, lib in (("asm", None), ("noasm", alt)):
+        env = dict(os.environ)
+        if lib:
+            env["GTOP_HIP_LIB"] = lib
+        else:
+            env.pop("GTOP_HIP_LIB", None)
+        f = str(tmp_path / f"{name}.npz")
+        subprocess.check_call([sys.executable, "-c", script, f], env=env, timeout=300)
+        res[name] = np.load(f)
+    for k in res["asm"].files:
+        assert np.array_equal(res["asm"][k], res["noasm"][k]), k
