@@ -61,6 +61,7 @@ enum { GTOP_MMA_FTOL_REACHED = 3, GTOP_MMA_XTOL_REACHED = 4, GTOP_MMA_MAXEVAL_RE
 struct GtopEvalPlan {
   int spl, nt;
   bool is_long;
+  int nw;   // wavefronts per trajectory: 2 for 7 .. 12 segments at ten lanes per segment (small batches), else 1
 };
 // The launch rule.  pinned_spl: 0 = auto, 3 or 6; for_optimizer: one trajectory per wavefront (the optimizer loop and
 // the evaluations of its multi-launch forms).  false: the request cannot be served (m < 2, spl 3 with more than 6

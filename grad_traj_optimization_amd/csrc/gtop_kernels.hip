@@ -620,9 +620,13 @@ constexpr int gtop_wave_budget() {
                                                                                                                      : MINW;
 }
 
+// NW = 2: ONE trajectory of 7 .. 12 segments over TWO wavefronts at ten lanes per segment (a 128-thread workgroup;
+// wavefront w holds segments 6w .. 6w + 5; the tile is shared and one workgroup barrier sits in front of the
+// gather) — for batches too small to fill the chip with one wavefront per trajectory, where six samples per lane
+// on one wavefront are simply the longer chain (B = 1, 10 segments — the NLopt callback on the reference's own scene).
 template <typename R, bool WIDE, int SPL, int NT, bool COLLI, int MINW, typename MM = GtopNoMma, bool DYN = false,
-          bool LONG = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(gtop_wave_budget<R, WIDE, MM, SPL, MINW, DYN, LONG>())))
+          bool LONG = false, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(gtop_wave_budget<R, WIDE, MM, SPL, MINW, DYN, LONG>())))
 gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df, const R *__restrict__ arg_T,
                       const R *__restrict__ arg_sdf, int arg_B, int arg_m, int arg_t_stride, int arg_nx, int arg_ny,
                       int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K, const MM st) {
@@ -634,21 +638,23 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   a.nx = arg_nx; a.ny = arg_ny; a.nz = arg_nz;
   constexpr int LPS = kSamples / SPL;   // lanes per segment
   constexpr int SPW = 64 / LPS;         // segment slots per wavefront
-  constexpr int kStride = red_stride(SPL);
+  constexpr int kStride = NW == 2 ? ((2 * LPS * SPW) | 1) : red_stride(SPL);   // (two wavefronts: 120 busy lanes)
   constexpr int kMVc = SPL == 6 ? 128 : 64;   // rows of the optimizer loop's LDS vectors: n <= 45 resp. 99 variables
   static_assert(SPL == 3 || SPL == 6, "10 or 5 lanes per segment");
   static_assert(SPL == 3 || MINW >= 3, "six samples per lane: one (pair) at a time only");
   static_assert(NT == 1 || NT == 2, "one or two trajectories per wavefront");
   static_assert(!LONG || (SPL == 6 && NT == 1), "more than 12 segments: five lanes per segment, one trajectory");
   static_assert(!DYN || (COLLI && MINW >= 3), "the velocity/acceleration block lives in the sample loop, one sample at a time");
+  static_assert(NW == 1 || (NW == 2 && SPL == 3 && NT == 1 && !LONG && !MMA), "two wavefronts per trajectory: plain evaluation at ten lanes per segment");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   R *tile = reinterpret_cast<R *>(smem_raw);   // [19][kStride] (+ [kRounds*64] gradient for the optimizer update)
   GTOP_STAMP(0);
   GTOP_STAMP_HWID();
-  const int lane = threadIdx.x;
+  const int lane = NW == 2 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+  const int wave = NW == 2 ? (int)(threadIdx.x >> 6) : 0;   // which half of the trajectory's segments
   const int m = a.m, ndp = 3 * m - 3, n = 3 * ndp;
   if constexpr (LONG) __builtin_assume(m > SPW);
-  else __builtin_assume(m >= 2 && NT * m <= SPW);
+  else __builtin_assume(m >= 2 && NT * m <= NW * SPW);
   __builtin_assume(lane >= 0 && lane < 64);
   const int tstride = LONG ? ((LPS * m) | 1) : kStride;    // row stride of the tile (LONG: 5 m columns, made odd)
   const int kMV = LONG ? ((n + 63) & ~63) : kMVc;          // rows of the optimizer loop's LDS vectors
@@ -667,13 +673,14 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   const int grp = grp_ok ? grp_raw : ngroups - 1;
   const int b0 = grp * NT;
 
-  const int slot = lane / LPS, li = lane - slot * LPS;
+  const int slot_w = lane / LPS, li = lane - slot_w * LPS;   // segment slot within the wavefront, lane within the segment
+  const int slot = wave * SPW + slot_w;
   int tl = 0, s = slot;
   if constexpr (NT == 2) {
     tl = s >= m;
     s -= tl * m;
   }
-  bool seg_ok = grp_ok & (slot < NT * m) & (b0 + tl < a.B);   // (LONG: set per chunk, below)
+  bool seg_ok = grp_ok & (slot_w < SPW) & (slot < NT * m) & (b0 + tl < a.B);   // (LONG: set per chunk, below)
   if (!seg_ok) { tl = 0; s = 0; }   // idle lanes shadow the first segment: finite data, results never read
 
   unsigned long long t_launch = 0ull;
@@ -746,14 +753,15 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     }
   }
   [[maybe_unused]] R cost_run = (R)0;   // LONG: this lane's share of the cost over its chunks
-  constexpr int kRounds = LONG ? 1 : (NT * 9 * (SPW / NT - 1) + 63) / 64;
+  constexpr int kRounds = LONG ? 1 : (NT * 9 * (NW * SPW / NT - 1) + 64 * NW - 1) / (64 * NW);
+  const int tid = NW == 2 ? (int)threadIdx.x : lane;
   int offA[kRounds], offB[kRounds];     // (filled below, while the inputs are on their way)
   bool okq[kRounds];
   bool cost_lane = false;
   for (int ch = 0; ch < nchunks; ++ch) {
   if constexpr (LONG) {
-    s = ch * SPW + slot;
-    seg_ok = grp_ok & (slot < SPW) & (s < m);
+    s = ch * SPW + slot_w;
+    seg_ok = grp_ok & (slot_w < SPW) & (s < m);
     if (!seg_ok) s = 0;
   }
   // ---- inputs: two waypoints' (p, v, a) per axis and T_s, straight from HBM/L2 (the optimizer loop: from LDS) ----
@@ -788,7 +796,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // wpt (entry 2 der)  (:425-432); tile[v][lane] holds entry v of lane's segment.
 #pragma unroll
   for (int r = 0; r < (LONG ? 0 : kRounds); ++r) {
-    const int qi = lane + 64 * r;
+    const int qi = tid + 64 * NW * r;
     int tq = 0, i = qi;
     if constexpr (NT == 2) {
       tq = i >= n;
@@ -811,7 +819,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // the same way (a trajectory's result must not depend on its place in the pair).
   const int cs = lane - 48;
   const int ct = NT == 2 ? cs >> 3 : 0, csi = NT == 2 ? cs & 7 : cs;   // trajectory, segment
-  cost_lane = !LONG & (cs >= 0) & (csi < m);
+  cost_lane = !LONG & (wave == NW - 1) & (cs >= 0) & (csi < m);   // (two wavefronts: the second one's lanes 48 ..)
   if (cost_lane) offA[kRounds - 1] = 18 * kStride + (ct * m + csi) * LPS;
   const R ws = a.ws;   // the launcher has applied :412-415 (step 1 -> ws = 0): `step` is not read here
   const R wc = a.wc;
@@ -1165,14 +1173,18 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   } else {
   if (lane < LPS * SPW) {
 #pragma unroll
-    for (int v = 0; v < kRedVals; ++v) tile[v * kStride + lane] = acc[v];   // (columns of idle slots are never read)
+    for (int v = 0; v < kRedVals; ++v) tile[v * kStride + wave * (LPS * SPW) + lane] = acc[v];   // (columns of idle slots are never read)
   }
   }
   GTOP_STAMP(8);   // A^-T + tile writes issued
   GTOP_STAMP(9);
   }   // chunk
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
-  __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
+  if constexpr (NW == 2) {
+    __syncthreads();   // the other wavefront's half of the tile
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // writers and readers are this wavefront's own lanes,
+    __builtin_amdgcn_wave_barrier();                          // whose LDS operations execute in order
+  }
   R csum_seg = (R)0;
   R *gl = tile + kTileRows * tstride;   // [kRounds*64] (LONG: [kMV]): the gradient for the optimizer update (MMA only)
   if constexpr (LONG) {
@@ -1208,7 +1220,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     if constexpr (MMA) {
       if (okq[r]) gl[lane + 64 * r] = gq;   // consumed below; nothing leaves the chip
     } else {
-      if (okq[r]) a.grad[(size_t)b0 * n + lane + 64 * r] = gq;
+      if (okq[r]) a.grad[(size_t)b0 * n + tid + 64 * NW * r] = gq;
     }
   }
   // ---- cost (:417-418): every term is already weighted; lanes 48.. hold the segment sums ----
@@ -1220,9 +1232,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     if constexpr (NT == 2) {
       if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
       if (grp_ok & (lane == 63) & (b0 + 1 < a.B)) a.cost[b0 + 1] = cpart + (R)1e-3;
-    } else if constexpr (SPW > 8 && !MMA) {
+    } else if constexpr (NW * SPW > 8 && !MMA) {
       cpart += gtop_dpp_move<0x118>(cpart);   // row_shr:8 -> lane 63 holds lanes 48..63 (up to 12 segments)
-      if (grp_ok & (lane == 63)) a.cost[b0] = cpart + (R)1e-3;
+      if (grp_ok & (wave == NW - 1) & (lane == 63)) a.cost[b0] = cpart + (R)1e-3;
     } else if constexpr (MMA) {
       // f(xcur) to every lane, then this wavefront's optimizer step for its trajectory
       constexpr int kCostLane = SPW > 8 ? 63 : 55;
@@ -1281,6 +1293,9 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
   return (unsigned long long)nx * ny < (1ull << 24) && nz < (1 << 24) && (nvox + 2) * elem < (1ull << 32);
 }
 
+#ifndef GTOP_TWO_WAVES_UP_TO
+#define GTOP_TWO_WAVES_UP_TO 1024   // trajectories of 7 .. 12 segments: two wavefronts each up to this batch (2 048 wavefronts)
+#endif
 #ifndef GTOP_WAVE_MINW3_FROM
 #define GTOP_WAVE_MINW3_FROM 3072   // batches that put a third wavefront on a SIMD (1 024 SIMDs)
 #endif
@@ -1290,7 +1305,8 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 static size_t wave_lds_bytes(const GtopEvalPlan &p, int m, size_t elem, bool mma) {
   if (!p.is_long) {
     const int kmv = p.spl == 6 ? 128 : 64;
-    return (size_t)(kRedVals * red_stride(p.spl) + 128 + (mma ? 8 * kmv + 32 : 0)) * elem;
+    const int stride = p.nw == 2 ? 121 : red_stride(p.spl);
+    return (size_t)(kRedVals * stride + 128 + (mma ? 8 * kmv + 32 : 0)) * elem;
   }
   const int n = 9 * (m - 1), kmv = (n + 63) & ~63, tstride = ((kSamples / 6) * m) | 1;
   return ((size_t)18 * tstride + (mma ? (size_t)9 * kmv + 18 + m + 8 : 0)) * elem;
@@ -1305,8 +1321,17 @@ static size_t wave_lds_bytes(const GtopEvalPlan &p, int m, size_t elem, bool mma
 bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimizer, GtopEvalPlan *plan) {
   if (m < 2 || (pinned_spl != 0 && pinned_spl != 3 && pinned_spl != 6)) return false;
   GtopEvalPlan p{};
+  p.nw = 1;
   if (m <= 6) p.spl = pinned_spl ? pinned_spl : ((elem == 4 && B >= 8192 && !for_optimizer) ? 6 : 3);
-  else if (pinned_spl == 3) return false;   // ten lanes per segment: six segments fill the wavefront
+  else if (m <= 12 && !for_optimizer && pinned_spl != 6 &&
+           (pinned_spl == 3 || B <= (elem == 4 ? GTOP_TWO_WAVES_UP_TO / 2 : GTOP_TWO_WAVES_UP_TO))) {
+    // 7 .. 12 segments, a batch that leaves SIMDs idle with one wavefront per trajectory: two wavefronts per
+    // trajectory at ten lanes per segment (measured on one box, 12 segments, fp64: B = 1 3.6 us against 5.8 on one
+    // wavefront, 256: 4.1 / 6.2, 1 024: 6.2 / 7.0, 1 280: 9.1 / 9.4; fp32, whose one-wavefront body runs packed
+    // pairs: 512: 4.9 / 7.1, 768: 5.1 / 4.9)
+    p.spl = 3;
+    p.nw = 2;
+  } else if (pinned_spl == 3) return false;   // ten lanes per segment: six segments fill a wavefront, twelve fill two
   else p.spl = 6;
   p.is_long = m > 12;
   p.nt = (p.spl == 6 && 2 * m <= 12 && !for_optimizer) ? 2 : 1;
@@ -1322,17 +1347,20 @@ using WaveKernelFn = void (*)(const R *, const R *, const R *, const R *, int, i
                               const GtopKernelArgs<R>, const GtopWaveConsts<R>, const MM);
 
 // one geometry: the collision-free, the ordinary and the DYN instantiation (DYN: one sample at a time, MINW >= 3)
-template <typename R, bool WIDE, int SPL, int NT, int MINW, typename MM, bool LONG>
+template <typename R, bool WIDE, int SPL, int NT, int MINW, typename MM, bool LONG, int NW = 1>
 static WaveKernelFn<R, MM> pick_body(bool colli, bool dyn) {
-  if (!colli) return gtop_eval_wave_kernel<R, WIDE, SPL, NT, false, MINW, MM, false, LONG>;   // (:346: no sample loop, no DYN)
-  if (dyn) return gtop_eval_wave_kernel<R, WIDE, SPL, NT, true, (MINW < 3 ? 3 : MINW), MM, true, LONG>;
-  return gtop_eval_wave_kernel<R, WIDE, SPL, NT, true, MINW, MM, false, LONG>;
+  if (!colli) return gtop_eval_wave_kernel<R, WIDE, SPL, NT, false, MINW, MM, false, LONG, NW>;   // (:346: no sample loop, no DYN)
+  if (dyn) return gtop_eval_wave_kernel<R, WIDE, SPL, NT, true, (MINW < 3 ? 3 : MINW), MM, true, LONG, NW>;
+  return gtop_eval_wave_kernel<R, WIDE, SPL, NT, true, MINW, MM, false, LONG, NW>;
 }
 
 template <typename R, bool WIDE, typename MM>
 static WaveKernelFn<R, MM> pick_geometry(const GtopEvalPlan &p, int B, bool colli, bool dyn) {
   constexpr bool MMA = !std::is_same<MM, GtopNoMma>::value;
   if (p.is_long) return pick_body<R, WIDE, 6, 1, 3, MM, true>(colli, dyn);
+  if constexpr (!MMA) {
+    if (p.nw == 2) return pick_body<R, WIDE, 3, 1, 2, MM, false, 2>(colli, dyn);   // (small batches only: the latency structure)
+  }
   if (p.spl == 3) {
     // latency variant (every corner load of a lane in flight, 252 VGPRs) up to the batch that puts a third wavefront
     // on a SIMD; the optimizer loop at every size (its update's working set spills a 168-VGPR budget); 64-bit field
@@ -1383,7 +1411,7 @@ static hipError_t launch_wave(const GtopKernelArgs<R> &args, const MM &st, const
     s.grad = wa.grad ? wa.grad + (size_t)b0 * n : nullptr;
     const int groups = (s.B + plan.nt - 1) / plan.nt;
     const int grid = 8 * ((groups + 7) / 8);   // the kernel deals its workgroups over 8 XCD-contiguous ranges
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), smem, stream, s.x, s.Df, s.T, s.sdf, s.B, s.m, s.t_stride, s.nx, s.ny,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * plan.nw), smem, stream, s.x, s.Df, s.T, s.sdf, s.B, s.m, s.t_stride, s.nx, s.ny,
                        s.nz, s, GtopWaveConsts<R>{}, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1401,7 +1429,7 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &p
 // the optimizer loop: st.iters evaluations at st.xcur, each followed by the CCSA-MMA update, in one launch (fp64)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
                                 bool dyn, hipStream_t stream) {
-  if (plan.nt != 1) return hipErrorInvalidValue;
+  if (plan.nt != 1 || plan.nw != 1) return hipErrorInvalidValue;
   return launch_wave<double, GtopMmaState>(args, st, plan, dyn, stream);
 }
 

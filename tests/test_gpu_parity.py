@@ -98,8 +98,9 @@ def test_fp64_parity_host_api(scene, oracle_mod, m, kw):
 @pytest.mark.parametrize("spl", [0, 3, 6])
 @pytest.mark.parametrize("waves", [0, 1])
 def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, waves):
-    """Samples per lane (ten or five lanes per segment, one or two trajectories per wavefront, chunks of 12 segments
-    past 12) only changes the work split.  Ten lanes per segment hold up to 6 segments: refused beyond."""
+    """Samples per lane (ten or five lanes per segment, one or two trajectories per wavefront, two wavefronts per
+    trajectory, chunks of 12 segments past 12) only changes the work split.  Ten lanes per segment hold up to 6 segments
+    per wavefront, 12 on two: refused beyond."""
     mp, ctx, sdf = scene
     b = problem.make_trajectories(23, m, mp, seed=200 + m,    # odd: exercises a partial last pair / padding workgroups
                                   step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0))
@@ -108,7 +109,7 @@ def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, wave
     ctx.set_params(**kw)
     ctx.set_problem(b.T, b.Df)
     try:
-        if spl == 3 and m > 6:
+        if spl == 3 and m > 12:
             with pytest.raises(gtop.GtopError) as e:
                 ctx.eval_batch(b.x)
             assert e.value.code == 1

@@ -77,7 +77,7 @@ def test_edge_cases_of_the_sample_loop(scene, oracle_mod, dtype, spl):
 
 
 @pytest.mark.parametrize("kw", [dict(wc=0.0), dict(wc=5e-5), dict(step=1), dict(ws=0.0), dict(ws=20.0, wc=1.0)])
-@pytest.mark.parametrize("spl,m", [(3, 6), (6, 6), (6, 12)])
+@pytest.mark.parametrize("spl,m", [(3, 6), (6, 6), (6, 12), (3, 12), (3, 7)])
 def test_parameter_sets_and_the_collision_free_instantiation(scene, oracle_mod, spl, m, kw):
     """|wc| < 1e-4 skips the sample loop (:346: the COLLI = false instantiation); step 1 drops the jerk weight (:412-415,
     applied by the launcher)."""
@@ -87,6 +87,31 @@ def test_parameter_sets_and_the_collision_free_instantiation(scene, oracle_mod, 
     c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params(**kw))
     rc, rg = scenes.rel_err(c, g, c_ref, g_ref)
     assert rc <= TOL64 and rg <= TOL64, (rc, rg)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("m", [7, 8, 10, 12])
+@pytest.mark.parametrize("B", [1, 23, 1024, 1025])
+def test_two_wavefronts_per_trajectory(scene, oracle_mod, dtype, m, B):
+    """7 .. 12 segments at ten lanes per segment over two wavefronts of one workgroup (the auto rule up to 1 024
+    trajectories; five lanes per segment on one wavefront past that): against the oracle, with out-of-map samples and
+    a 29-sample segment in the batch, and — fp64 — bit for bit the same row whatever the batch around it."""
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(B, m, mp, seed=640 + m, step_len=(0.5, 1.2), boundary="random")
+    x, T = b.x.copy(), b.T.copy()
+    x[0, 0] += 30.0                      # row 0 leaves the map
+    T[B // 2, m - 1] = 0.03              # a 29-sample segment in the second wavefront's half
+    bb = problem.Batch(b.waypoints, T, b.Df, x, m)
+    c, g = _run(ctx, bb, 0, dtype)
+    idx = np.arange(B) if B <= 64 else np.r_[0:40, B // 2 - 2:B // 2 + 2, B - 40:B]
+    c_ref, g_ref, _ = oracle_mod.eval_batch(T[idx], b.Df[idx], x[idx], sdf, oracle_mod.make_params(), nthreads=8)
+    rc, rg = scenes.rel_err(c[idx], g[idx], c_ref, g_ref)
+    tol = TOL64 if dtype == "f64" else 2e-3          # (fp32: 30 m outside the map is beyond its digits)
+    assert rc <= tol and rg <= tol, (rc, rg)
+    if B == 1024 and dtype == "f64":                  # the same body for a batch of 3 of its rows
+        sub = [0, 511, 1023]
+        cs, gs = _run(ctx, problem.Batch(b.waypoints[sub], T[sub], b.Df[sub], x[sub], m), 0, dtype)
+        assert np.array_equal(cs, c[sub]) and np.array_equal(gs, g[sub])
 
 
 def test_rows_do_not_depend_on_their_place(scene):
