@@ -74,5 +74,5 @@ def test_no_kernel_spills_to_scratch_memory():
     assert len(rows) >= 60
     bad = [r for r in rows if r["scratch"] or r["vgpr_spill"]]
     assert not bad, bad
-    hot = [r for r in rows if r["kernel"].startswith("gtop_eval_wave_kernel<double, false, 3, 1, true, 2, GtopNoMma")]
+    hot = [r for r in rows if r["kernel"].startswith("gtop_eval_wave_kernel<double, false, 3, 1, true, 2, GtopNoMma, false, false, 1>")]
     assert len(hot) == 1 and hot[0]["sgpr_spill"] == 0 and hot[0]["waves_per_simd"] == 2, hot
