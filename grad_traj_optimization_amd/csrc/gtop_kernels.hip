@@ -1293,6 +1293,9 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
   return (unsigned long long)nx * ny < (1ull << 24) && nz < (1 << 24) && (nvox + 2) * elem < (1ull << 32);
 }
 
+#ifndef GTOP_TWO_PER_WAVE_F64_FROM
+#define GTOP_TWO_PER_WAVE_F64_FROM 12288
+#endif
 #ifndef GTOP_TWO_WAVES_UP_TO
 #define GTOP_TWO_WAVES_UP_TO 1024   // trajectories of 7 .. 12 segments: two wavefronts each up to this batch (2 048 wavefronts)
 #endif
@@ -1313,8 +1316,8 @@ static size_t wave_lds_bytes(const GtopEvalPlan &p, int m, size_t elem, bool mma
 }
 
 // The launch rule (measured).  Up to 6 segments: ten lanes per segment, one wavefront per
-// trajectory, at EVERY batch size in fp64 and up to 8 192 trajectories in fp32, where the packed-fp32 kernel with two
-// trajectories per wavefront at five lanes per segment takes over.  7 .. 12 segments: five lanes per segment, one
+// trajectory, up to 12 288 trajectories in fp64 and 8 192 in fp32, where two trajectories per wavefront at five lanes
+// per segment take over (fp32: packed sample pairs).  7 .. 12 segments: five lanes per segment, one
 // trajectory per wavefront.  Past 12: the same wavefront walks the segments 12 at a time (LONG).  The optimizer loop
 // always has one trajectory per wavefront.  pinned_spl = 3 or 6 overrides the lanes-per-segment choice where it can
 // be honoured (3: up to 6 segments).
@@ -1322,7 +1325,11 @@ bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimize
   if (m < 2 || (pinned_spl != 0 && pinned_spl != 3 && pinned_spl != 6)) return false;
   GtopEvalPlan p{};
   p.nw = 1;
-  if (m <= 6) p.spl = pinned_spl ? pinned_spl : ((elem == 4 && B >= 8192 && !for_optimizer) ? 6 : 3);
+  // (two trajectories per wavefront at five lanes per segment amortise the per-lane set-up — coefficients, jerk term,
+  // A^-T — over six samples instead of three: fewer instructions per trajectory, longer chains per wavefront; it wins
+  // once the batch fills the chip several times over — measured on one box, fp64: B = 8 192 19.6 us either way,
+  // 16 384: 32.5 against 34.6, 65 536: 118 against 128; fp32, packed pairs: from 8 192)
+  if (m <= 6) p.spl = pinned_spl ? pinned_spl : ((B >= (elem == 4 ? 8192 : GTOP_TWO_PER_WAVE_F64_FROM) && !for_optimizer) ? 6 : 3);
   else if (m <= 12 && !for_optimizer && pinned_spl != 6 &&
            (pinned_spl == 3 || B <= (elem == 4 ? GTOP_TWO_WAVES_UP_TO / 2 : GTOP_TWO_WAVES_UP_TO))) {
     // 7 .. 12 segments, a batch that leaves SIMDs idle with one wavefront per trajectory: two wavefronts per
