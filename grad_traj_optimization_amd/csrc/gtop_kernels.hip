@@ -896,9 +896,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // the division inside the rare branch (the compiler otherwise computes it up front for everybody).
     auto tiny_dt = [&]() {
       R Tq = T;
-#ifndef GTOP_NO_TINY_OPAQUE
       asm volatile("" : "+v"(Tq));
-#endif
       return Tq / (R)30.0;
     };
     const R aw_all = pen_alpha * wdt;
@@ -1213,9 +1211,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   for (int r = 0; r < kRounds; ++r) {
     const R sa = tree_sum<R, LPS>(tile + offA[r]), sb = tree_sum<R, LPS>(tile + offB[r]);
     R gq = (sa + sb) + K.eps;
-#ifndef GTOP_NO_GQ_PIN
     asm volatile("" : "+v"(gq));   // both reads of the round in front of the store's branch: one LDS round trip, not two
-#endif
     if (r == kRounds - 1 && cost_lane) csum_seg = sa;
     if constexpr (MMA) {
       if (okq[r]) gl[lane + 64 * r] = gq;   // consumed below; nothing leaves the chip
