@@ -265,4 +265,105 @@ double GradTrajOptimizer::costFunc(const std::vector<double> &x, std::vector<dou
   return gtop_cost_nlopt((unsigned)x.size(), x.data(), grad.data(), gtop->ctx_);
 }
 
+// ---- GradTrajBatch ----------------------------------------------------------------------------------------------
+
+GradTrajBatch::GradTrajBatch(const std::vector<int> &devices, const GradTrajOptimizer::Config &cfg) : cfg_(cfg) {
+  last_status_ = gtop_group_create(&grp_, devices.data(), (int)devices.size());
+  if (last_status_ != GTOP_OK) grp_ = nullptr;
+}
+
+GradTrajBatch::~GradTrajBatch() {
+  if (grp_) gtop_group_destroy(grp_);
+}
+
+int GradTrajBatch::devices() const { return grp_ ? gtop_group_size(grp_) : 0; }
+const char *GradTrajBatch::gatherBackend() const { return grp_ ? gtop_group_gather_backend(grp_) : ""; }
+const char *GradTrajBatch::lastError() const { return grp_ ? gtop_group_last_error(grp_) : "gtop_group_create failed"; }
+
+void GradTrajBatch::initSDFMap(Vec3 map_size_3d, Vec3 origin, double resolution) {
+  if (grp_) last_status_ = gtop_group_init_sdf_map(grp_, map_size_3d.data(), origin.data(), resolution);
+}
+
+void GradTrajBatch::updateSDFMap(const std::vector<Vec3> &obs) {
+  if (grp_) last_status_ = gtop_group_update_sdf_map(grp_, obs.empty() ? nullptr : obs[0].data(), (int)obs.size());
+}
+
+void GradTrajBatch::setPaths(const std::vector<std::vector<Vec3>> &way_points) {
+  const int B = (int)way_points.size(), npts = B ? (int)way_points[0].size() : 0;
+  bool same = B > 0 && npts >= 3;
+  for (const auto &w : way_points) same = same && (int)w.size() == npts;
+  if (!grp_ || !same) {
+    last_status_ = GTOP_ERR_INVALID;
+    return;
+  }
+  const int m = npts - 1, num_dp = 3 * m - 3;
+  B_ = B;
+  m_ = m;
+  path_.assign((size_t)B * npts * 3, 0.0);
+  T_.assign((size_t)B * m, 0.0);
+  Df_.assign((size_t)B * 18, 0.0);
+  x_.assign((size_t)B * 3 * num_dp, 0.0);
+  for (int b = 0; b < B; ++b) {
+    double *p = &path_[(size_t)b * npts * 3];
+    for (int i = 0; i < npts; ++i)
+      for (int a = 0; a < 3; ++a) p[i * 3 + a] = way_points[b][i][a];
+    for (int i = 0; i < m; ++i) {   // :73-81 (only segment 0 gets init_time: the `i == size()` clause never holds)
+      const double dx = p[i * 3] - p[(i + 1) * 3], dy = p[i * 3 + 1] - p[(i + 1) * 3 + 1], dz = p[i * 3 + 2] - p[(i + 1) * 3 + 2];
+      T_[(size_t)b * m + i] = std::sqrt(dx * dx + dy * dy + dz * dz) / cfg_.mean_v + (i == 0 ? cfg_.init_time : 0.0);
+    }
+    for (int a = 0; a < 3; ++a) {   // getInitialD (src/qp_generator.cpp:407-451): positions only, zero velocity / acceleration
+      Df_[(size_t)b * 18 + a * 6 + 0] = p[a];
+      Df_[(size_t)b * 18 + a * 6 + 3] = p[m * 3 + a];
+      for (int k = 1; k < m; ++k) x_[(size_t)b * 3 * num_dp + (size_t)a * num_dp + (k - 1) * 3] = p[k * 3 + a];
+    }
+  }
+  last_status_ = gtop_group_set_problem(grp_, B, m, T_.data(), m, Df_.data());
+}
+
+bool GradTrajBatch::optimizeTrajectories(int step) {
+  if (!grp_ || B_ == 0) return true;   // (:242 — always true)
+  gtop_params p;
+  p.ws = cfg_.ws; p.wc = cfg_.wc;
+  p.alpha = cfg_.alpha; p.r = cfg_.r; p.d0 = cfg_.d0;
+  p.alpha_v = cfg_.alpha_v; p.r_v = cfg_.r_v; p.v0 = cfg_.v0;
+  p.alpha_a = cfg_.alpha_a; p.r_a = cfg_.r_a; p.a0 = cfg_.a0;
+  p.step = step;
+  p.enable_dyn = cfg_.enable_dyn;
+  if ((last_status_ = gtop_group_set_params(grp_, &p)) != GTOP_OK) return true;
+  const int npts = m_ + 1;
+  const size_t n = 9 * (size_t)(m_ - 1);
+  std::vector<double> lb((size_t)B_ * n), ub((size_t)B_ * n);
+  gtop_default_bounds(B_, m_, path_.data(), cfg_.bos, cfg_.vos, cfg_.aos, lb.data(), ub.data());   // :151-179
+  (void)npts;
+  const double maxtime = step == OPT_FIRST_STEP ? cfg_.time_limit_1 : (step == OPT_SECOND_STEP ? cfg_.time_limit_2 : 0.0);
+  const gtop_stop stop = {cfg_.max_evals > 0 ? cfg_.max_evals : (1 << 24), 0.0, 0.0, maxtime};   // :144-148
+  min_cost_.assign(B_, 0.0);
+  nevals_.assign(B_, 0);
+  std::vector<int32_t> nev(B_), code(B_);
+  last_status_ = gtop_group_optimize_batch_ex(grp_, B_, x_.data(), lb.data(), ub.data(), &stop, min_cost_.data(), nev.data(),
+                                              code.data());
+  for (int b = 0; b < B_; ++b) nevals_[b] = nev[b];
+  return true;
+}
+
+void GradTrajBatch::getCoefficient(int b, Matrix &coeff) const {
+  coeff.resize(m_, 18);
+  if (b < 0 || b >= B_) return;
+  const int num_dp = 3 * m_ - 3;
+  const double *df = &Df_[(size_t)b * 18], *x = &x_[(size_t)b * 3 * num_dp];
+  for (int a = 0; a < 3; ++a) {
+    auto wp = [&](int j, int der) -> double {
+      if (j == 0) return df[a * 6 + der];
+      if (j == m_) return df[a * 6 + 3 + der];
+      return x[(size_t)a * num_dp + 3 * (j - 1) + der];
+    };
+    for (int s = 0; s < m_; ++s) {
+      const double d[6] = {wp(s, 0), wp(s + 1, 0), wp(s, 1), wp(s + 1, 1), wp(s, 2), wp(s + 1, 2)};
+      double c[6];
+      quintic_from_boundary(d, T_[(size_t)b * m_ + s], c);
+      for (int j = 0; j < 6; ++j) coeff(s, 6 * a + j) = c[j];
+    }
+  }
+}
+
 }  // namespace gtop_amd

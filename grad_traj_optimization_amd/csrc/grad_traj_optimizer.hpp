@@ -116,6 +116,46 @@ class GradTrajOptimizer {
   int last_evals_ = 0;
 };
 
+// ---------------------------------------------------------------------------
+// GradTrajBatch — the same public steps for MANY trajectories at once, on one or several GPUs (not in the reference,
+// which optimises one trajectory per object: a planner that holds N candidate paths runs N objects one after the other).
+// initSDFMap / updateSDFMap / setPaths / optimizeTrajectories / getCoefficient mirror GradTrajOptimizer's methods with a
+// batch index; underneath is a gtop_group (include/gtop.h): the distance field replicated on every listed device, the
+// batch in contiguous slices, the whole optimisation of a slice ONE launch on its device.
+// ---------------------------------------------------------------------------
+class GradTrajBatch {
+ public:
+  // devices: HIP ordinals, one slice of the batch each (an ordinal may repeat); cfg as for GradTrajOptimizer
+  explicit GradTrajBatch(const std::vector<int> &devices, const GradTrajOptimizer::Config &cfg = GradTrajOptimizer::Config());
+  ~GradTrajBatch();
+  GradTrajBatch(const GradTrajBatch &) = delete;
+  GradTrajBatch &operator=(const GradTrajBatch &) = delete;
+
+  void initSDFMap(Vec3 map_size_3d, Vec3 origin, double resolution);
+  void updateSDFMap(const std::vector<Vec3> &obs);
+  // B waypoint lists of the same length (m + 1 >= 3 points each): segment times, Df and the straight-line start as
+  // GradTrajOptimizer::setPath makes them (src/grad_traj_optimizer.cpp:67-110)
+  void setPaths(const std::vector<std::vector<Vec3>> &way_points);
+  // every trajectory's LD_MMA run (:128-243), all at once; stop rules: cfg.max_evals and the step's time limit
+  bool optimizeTrajectories(int step);
+  void getCoefficient(int b, Matrix &coeff) const;               // trajectory b, m x 18
+  const std::vector<double> &costs() const { return min_cost_; }  // the minimum each trajectory reached
+  const std::vector<int> &evaluations() const { return nevals_; }
+  int size() const { return B_; }
+  int devices() const;
+  const char *gatherBackend() const;                              // "rccl" / "copy" (gtop_group_gather_backend)
+  bool ok() const { return grp_ != nullptr && last_status_ == GTOP_OK; }
+  const char *lastError() const;
+
+ private:
+  GradTrajOptimizer::Config cfg_;
+  gtop_group *grp_ = nullptr;
+  int last_status_ = GTOP_OK;
+  int B_ = 0, m_ = 0;
+  std::vector<double> path_, T_, Df_, x_, min_cost_;
+  std::vector<int> nevals_;
+};
+
 }  // namespace gtop_amd
 
 #endif  // GTOP_AMD_GRAD_TRAJ_OPTIMIZER_HPP_

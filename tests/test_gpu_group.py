@@ -96,3 +96,26 @@ def test_group_optimizer_and_errors(scene, gtop):
     with pytest.raises(gtop.GtopError):
         gtop.GtopGroup([0, 99])                           # no such device
     g.close()
+
+
+def test_cpp_batch_class_over_the_group(tmp_path):
+    """GradTrajBatch (csrc/grad_traj_optimizer.hpp): the C++ host side for MANY trajectories on the listed devices —
+    tests/cpp/batch_devices.cpp runs 200 copies of the reference's opti_node path (small offsets per copy) on three
+    members (device 0 three times) and, for five of them, the same problem through one GradTrajOptimizer object:
+    the same minimum and coefficients (the single-problem loop runs the same body, so to rounding of the final
+    evaluation only)."""
+    import json
+    import os
+    import subprocess
+    from tests import scenes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "grad_traj_optimization_amd", "gtop_batch_devices")
+    assert os.path.exists(exe), "build() did not produce gtop_batch_devices"
+    f = scenes.write_scene(tmp_path / "opti_node.txt", scenes.OPTI_NODE_MAP_SIZE, scenes.OPTI_NODE_ORIGIN,
+                           scenes.OPTI_NODE_RES, scenes.opti_node_obstacles(), scenes.OPTI_NODE_PATH)
+    out = subprocess.run([exe, str(f), "200", "30", "0", "0", "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout[out.stdout.index("{"):])
+    assert r["B"] == 200 and r["devices"] == 3 and r["gather"] == "copy"
+    assert r["min_evals"] == r["max_evals"] == 30
+    assert r["max_rel_cost_diff"] <= 1e-9 and r["max_coeff_diff"] <= 1e-9, r
