@@ -88,7 +88,7 @@ esdf_mark_kernel(const GtopGrid g, const double *__restrict__ pts, int npts,
 constexpr int kMaxChunks = 64;   // columns up to 4096 voxels
 
 __global__ void __launch_bounds__(256)
-esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out,
+esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out, uint16_t *__restrict__ out16,
               uint8_t *__restrict__ colany, int *__restrict__ n_empty_slabs) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_empty_slabs = 0;   // counted by the y sweep / esdf_rows_kernel, read by the x sweep
   __shared__ unsigned long long masks[4][kMaxChunks];
@@ -128,7 +128,10 @@ esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict
         }
         best = d < best ? d : best;
       }
-      if (z < nz) out[col * nz + z] = best >= kInf ? kInf : best * best;
+      if (z < nz) {
+        out[col * nz + z] = best >= kInf ? kInf : best * best;
+        if (out16) out16[col * nz + z] = (uint16_t)(best >= 256 ? 0xFFFF : best * best);   // min(value, 0xFFFF): esdf_y16_kernel
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -142,7 +145,7 @@ esdf_z_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict
 // square as an int made this sweep 2 us faster and the y sweep 2.4 us slower.
 template <int NCH>
 __global__ void __launch_bounds__(256)
-esdf_z_small_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out,
+esdf_z_small_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__restrict__ out, uint16_t *__restrict__ out16,
                     uint8_t *__restrict__ colany, int *__restrict__ n_empty_slabs) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_empty_slabs = 0;   // counted by the y sweep / esdf_rows_kernel, read by the x sweep
   constexpr int kFar = 1 << 20;   // "no occupied voxel on that side": farther than any column is long
@@ -167,7 +170,10 @@ esdf_z_small_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__re
 #pragma unroll
       for (int ko = 0; ko < NCH; ++ko) {
         const int z = ko * 64 + lane;
-        if (z < nz) out[col * nz + z] = kInf;
+        if (z < nz) {
+          out[col * nz + z] = kInf;
+          if (out16) out16[col * nz + z] = 0xFFFF;
+        }
       }
       continue;
     }
@@ -185,7 +191,10 @@ esdf_z_small_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__re
       const int d1 = mb ? lane - (63 - __clzll((long long)mb)) : kFar;
       const int d2 = ma ? (__ffsll((long long)ma) - 1) - lane : kFar;
       const int best = min(min(d1, d2), min(z - below, above - z));
-      if (z < nz) out[col * nz + z] = best >= (kFar >> 1) ? kInf : best * best;
+      if (z < nz) {
+        out[col * nz + z] = best >= (kFar >> 1) ? kInf : best * best;
+        if (out16) out16[col * nz + z] = (uint16_t)(best >= 256 ? 0xFFFF : best * best);   // min(value, 0xFFFF)
+      }
     }
   }
 }
@@ -251,6 +260,10 @@ template <> struct __attribute__((aligned(16))) IntV<4> { int v[4]; };
 
 template <int V>
 __device__ __forceinline__ IntV<V> load_v(const int *p) { return *reinterpret_cast<const IntV<V> *>(p); }
+
+// eight voxels as packed 16-bit squares, saturated at 0xFFFF (the packed sweeps: esdf_y16_kernel, esdf_x16_kernel)
+typedef unsigned short gtop_u16x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(16))) PkV { gtop_u16x2 p[4]; };
 
 // y sweep (sdf_map.cpp:328-346): out(x,y,z) = min over candidate columns v of (y-v)^2 + in(x,v,z).
 // 32-bit index arithmetic throughout (nvox < 2^31; ny, nz < 2^15 so that v*nz is a 24-bit product).
@@ -406,6 +419,198 @@ esdf_y_kernel(const GtopGrid g, const int *__restrict__ fin, int *__restrict__ f
     esdf_stamp(t0_stamp, tmax);
   }
 #endif
+}
+
+
+// The y sweep on packed 16-bit values (round 3): the scan is bound by the texture-address unit — a wave64 load costs
+// it 16 cycles whatever its width — so the z sweep leaves min(value, 0xFFFF) as 16-bit words beside its int32 output
+// and a lane here owns EIGHT voxels adjacent in z: a 16-byte load brings 8 voxels instead of 4, and the min-plus step
+// on two of them is one saturating v_pk_add_u16 + one v_pk_min_u16.  As in esdf_x16_kernel the packed scan returns
+// min(exact, 0xFFFF) for every voxel whatever the inputs (a saturated candidate, or a d^2 past 16 bits, can never
+// beat a minimum below 0xFFFF; unsaturated values are exact); a wavefront that ends with a saturated minimum (more than
+// 255 voxels to the nearest obstacle within the slab) redoes its voxels with the 32-bit scan on the int32 data.
+// Same candidate lists, same XCD placement, same outputs (int32 + 16-bit) as esdf_y_kernel<4, LOCAL>; nz % 8 == 0.
+template <bool LOCAL>
+__global__ void __launch_bounds__(256)
+esdf_y16_kernel(const GtopGrid g, const uint16_t *__restrict__ fin16, const int *__restrict__ fin, int *__restrict__ fout,
+                uint16_t *__restrict__ fout16, const int *__restrict__ cols, const int *__restrict__ rank,
+                const int *__restrict__ cnt, const uint8_t *__restrict__ colany, int *__restrict__ cnt_out) {
+  constexpr int U = 4, V = 8;   // candidates per round trip and side; voxels per lane
+  const int nyz = g.ny * g.nz;
+  const int ny = g.ny, nz = g.nz;
+  const int bps = (nyz / V + 255) >> 8;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int x = xcd + 8 * (j / bps);
+  const int r_raw = ((j % bps) * 256 + (int)threadIdx.x) * V;
+  __shared__ unsigned short s_cols[LOCAL ? kYLocalMax : 1];
+  __shared__ unsigned long long s_mask[LOCAL ? kYLocalMax / 64 : 1];
+  __shared__ int s_pref[LOCAL ? kYLocalMax / 64 + 1 : 1];
+  if (x >= g.nx) return;   // (workgroup-uniform)
+  if constexpr (LOCAL) {
+    if (threadIdx.x < 64) {  // one wavefront: ballots over the slab's column flags (as esdf_y_kernel)
+      const int lane = threadIdx.x;
+      const uint8_t *ca = colany + x * ny;
+      constexpr int kPre = 4;
+      int base = 0;
+      for (int y0 = 0; y0 < ny; y0 += 64 * kPre) {
+        bool f[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+          const int y = y0 + 64 * u + lane;
+          f[u] = (y < ny) && ca[y];
+        }
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+          const int y = y0 + 64 * u + lane;
+          if (y0 + 64 * u >= ny) break;
+          const unsigned long long mk = __ballot(f[u]);
+          if (f[u]) s_cols[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)y;
+          if (lane == 0) {
+            s_mask[(y0 >> 6) + u] = mk;
+            s_pref[(y0 >> 6) + u] = base;
+          }
+          base += __popcll(mk);
+        }
+      }
+      if (lane == 0) {
+        s_pref[(ny + 63) >> 6] = base;
+        if (j % bps == 0) {
+          cnt_out[x] = base;
+          if (base == 0) atomicAdd(cnt_out + g.nx, 1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // whole wavefronts only (the fallback below is decided per wavefront): lanes past the slab's end shadow its last
+  // lane with work and store nothing
+  const int wave_first = r_raw - ((int)threadIdx.x & 63) * V;
+  if (wave_first >= nyz) return;
+  const bool has_work = r_raw < nyz;
+  const int r = has_work ? r_raw : nyz - V;
+  const int i = x * nyz + r;
+  const int q = r / nz;                       // (nz % 8 == 0: the 8 voxels share q)
+  const int lbase = i - q * nz;               // (x, 0, z)
+  auto cx = [&](int k) -> int {
+    if constexpr (LOCAL) return s_cols[k];
+    else return cols[x * ny + k];
+  };
+  int c, k0;
+  if constexpr (LOCAL) {
+    c = s_pref[(ny + 63) >> 6];
+    k0 = s_pref[q >> 6] + __popcll(s_mask[q >> 6] & ((1ull << (q & 63)) - 1ull));
+  } else {
+    c = cnt[x];
+    k0 = rank[x * ny + q];
+  }
+  const int ka = k0 + ((k0 < c && cx(k0) == q) ? 1 : 0);   // the first candidate above q that is not q's own column
+  if (c == 0) {   // (workgroup-uniform) a slab without obstacles: nothing but "no obstacle"
+    if (has_work) {
+      IntV<4> inf;
+      inf.v[0] = inf.v[1] = inf.v[2] = inf.v[3] = kInf;
+      *reinterpret_cast<IntV<4> *>(fout + i) = inf;
+      *reinterpret_cast<IntV<4> *>(fout + i + 4) = inf;
+      if (fout16) *reinterpret_cast<uint4 *>(fout16 + i) = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
+    return;
+  }
+  auto splat = [](int d2) {
+    gtop_u16x2 s2;
+    s2.x = (unsigned short)d2;
+    s2.y = (unsigned short)d2;
+    return s2;
+  };
+  PkV best = *reinterpret_cast<const PkV *>(fin16 + i);
+  auto worst_of = [&]() {
+    const gtop_u16x2 w = __builtin_elementwise_max(__builtin_elementwise_max(best.p[0], best.p[1]),
+                                                   __builtin_elementwise_max(best.p[2], best.p[3]));
+    return max((int)w.x, (int)w.y);
+  };
+  int worst = worst_of();
+  // below q: candidates k0-1, k0-2, ... (ascending distance); indices clamped to the list's ends instead of masked
+  for (int k = k0 - 1; k >= 0; k -= U) {
+    const int d0 = q - cx(k);
+    if (__mul24(d0, d0) >= worst) break;   // in(v) >= 0: nothing farther can win (d0 >= 256: d0^2 > 0xFFFF >= worst)
+    int v[U];
+    PkV f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = cx(max(k - u, 0));
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = *reinterpret_cast<const PkV *>(fin16 + lbase + __mul24(v[u], nz));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int d = q - v[u];
+      const gtop_u16x2 dd = splat(min(__mul24(d, d), 0xFFFF));
+#pragma unroll
+      for (int p = 0; p < 4; ++p) best.p[p] = __builtin_elementwise_min(best.p[p], __builtin_elementwise_add_sat(f[u].p[p], dd));
+    }
+    worst = worst_of();
+  }
+  for (int k = ka; k < c; k += U) {
+    const int d0 = cx(k) - q;
+    if (__mul24(d0, d0) >= worst) break;
+    int v[U];
+    PkV f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = cx(min(k + u, c - 1));
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = *reinterpret_cast<const PkV *>(fin16 + lbase + __mul24(v[u], nz));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int d = v[u] - q;
+      const gtop_u16x2 dd = splat(min(__mul24(d, d), 0xFFFF));
+#pragma unroll
+      for (int p = 0; p < 4; ++p) best.p[p] = __builtin_elementwise_min(best.p[p], __builtin_elementwise_add_sat(f[u].p[p], dd));
+    }
+    worst = worst_of();
+  }
+  if (__any(worst == 0xFFFF)) {
+    // (wave-uniform) a minimum at or past 2^16 - 1 somewhere in the wavefront: the exact 32-bit scan of esdf_y_kernel
+    // for its voxels, four at a time
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const int ih = i + 4 * h;
+      const int *line = fin + lbase + 4 * h;
+      IntV<4> b32 = load_v<4>(fin + ih);
+      int w32 = max(max(b32.v[0], b32.v[1]), max(b32.v[2], b32.v[3]));
+      for (int k = k0 - 1; k >= 0; --k) {
+        const int vv = cx(k), d = q - vv, d2 = __mul24(d, d);
+        if (d2 >= w32) break;
+        const IntV<4> f = load_v<4>(line + __mul24(vv, nz));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b32.v[e] = min(b32.v[e], d2 + f.v[e]);
+        w32 = max(max(b32.v[0], b32.v[1]), max(b32.v[2], b32.v[3]));
+      }
+      for (int k = ka; k < c; ++k) {
+        const int vv = cx(k), d = vv - q, d2 = __mul24(d, d);
+        if (d2 >= w32) break;
+        const IntV<4> f = load_v<4>(line + __mul24(vv, nz));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b32.v[e] = min(b32.v[e], d2 + f.v[e]);
+        w32 = max(max(b32.v[0], b32.v[1]), max(b32.v[2], b32.v[3]));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b32.v[e] = b32.v[e] > kInf ? kInf : b32.v[e];
+      if (has_work) {
+        *reinterpret_cast<IntV<4> *>(fout + ih) = b32;
+        if (fout16) {
+          uint2 pk;
+          pk.x = (unsigned)min(b32.v[0], 0xFFFF) | ((unsigned)min(b32.v[1], 0xFFFF) << 16);
+          pk.y = (unsigned)min(b32.v[2], 0xFFFF) | ((unsigned)min(b32.v[3], 0xFFFF) << 16);
+          *reinterpret_cast<uint2 *>(fout16 + ih) = pk;
+        }
+      }
+    }
+    return;
+  }
+  if (has_work) {   // every value is below 0xFFFF: the 16-bit words ARE the exact minima
+    IntV<4> lo4, hi4;
+    lo4.v[0] = best.p[0].x; lo4.v[1] = best.p[0].y; lo4.v[2] = best.p[1].x; lo4.v[3] = best.p[1].y;
+    hi4.v[0] = best.p[2].x; hi4.v[1] = best.p[2].y; hi4.v[2] = best.p[3].x; hi4.v[3] = best.p[3].y;
+    *reinterpret_cast<IntV<4> *>(fout + i) = lo4;
+    *reinterpret_cast<IntV<4> *>(fout + i + 4) = hi4;
+    if (fout16) *reinterpret_cast<PkV *>(fout16 + i) = best;
+  }
 }
 
 // x sweep (sdf_map.cpp:348-364): out(q) = min_v ((q-v)^2 + in(v)), scanning outward; then
@@ -647,8 +852,6 @@ esdf_x_kernel(const GtopGrid g, const int *__restrict__ fin, double *__restrict_
 // likewise) can never beat a minimum below 0xFFFF and unsaturated ones are exact.  A wavefront that ends with a
 // saturated minimum (more than 255 voxels of free space, a line without obstacles) takes the 32-bit scan above for
 // its voxels instead.
-typedef unsigned short gtop_u16x2 __attribute__((ext_vector_type(2)));
-struct __attribute__((aligned(16))) PkV { gtop_u16x2 p[4]; };
 
 #ifndef GTOP_ESDF_X16_BLOCK
 #define GTOP_ESDF_X16_BLOCK 128
@@ -833,8 +1036,9 @@ bool gtop_esdf_supported(const GtopGrid &g) {
 size_t gtop_esdf_rows_ints(const GtopGrid &g) {
   const size_t ncol = (size_t)g.nx * g.ny;
   const size_t nvox = ncol * (size_t)g.nz;
-  // cols, rank, cnt (+ the count of empty slabs), colany (bytes), padding to 16 bytes, the y sweep's 16-bit output
-  return ((2 * ncol + (size_t)g.nx + 1 + (ncol + 3) / 4 + 3) & ~(size_t)3) + (nvox + 1) / 2;   // (cnt: nx + 1)
+  // cols, rank, cnt (+ the count of empty slabs), colany (bytes), padding to 16 bytes, the y sweep's 16-bit output, the
+  // z sweep's 16-bit output (each nvox 16-bit words, rounded up to 16 bytes)
+  return ((2 * ncol + (size_t)g.nx + 1 + (ncol + 3) / 4 + 3) & ~(size_t)3) + 2 * (((nvox + 1) / 2 + 3) & ~(size_t)3);   // (cnt: nx + 1)
 }
 
 hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,
@@ -843,17 +1047,31 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
   int *cols = rows, *rank = rows + ncol, *cnt = rows + 2 * ncol;
   uint8_t *colany = reinterpret_cast<uint8_t *>(rows + 2 * ncol + g.nx + 1);   // cnt[nx] = number of empty slabs
   uint16_t *f16 = reinterpret_cast<uint16_t *>(rows + ((2 * ncol + (size_t)g.nx + 1 + (ncol + 3) / 4 + 3) & ~(size_t)3));
+  const size_t nvox_all = ncol * (size_t)g.nz;
+  uint16_t *z16_buf = f16 + 2 * (((nvox_all + 1) / 2 + 3) & ~(size_t)3);   // behind the y sweep's 16-bit output
+#ifndef GTOP_ESDF_Y16
+#define GTOP_ESDF_Y16 1
+#endif
+#ifndef GTOP_ESDF_X16
+#define GTOP_ESDF_X16 1
+#endif
+#ifndef GTOP_ESDF_VEC
+#define GTOP_ESDF_VEC 4
+#endif
+  // the packed 16-bit y sweep (8 voxels per lane): where the packed x sweep runs and a lane's 8 voxels share a y
+  const bool y16k = GTOP_ESDF_Y16 && GTOP_ESDF_X16 && GTOP_ESDF_VEC == 4 && g.nz % 8 == 0;
+  uint16_t *z16 = y16k ? z16_buf : (uint16_t *)nullptr;
   const unsigned zblocks = (unsigned)((ncol + 3) / 4 < 65536 ? (ncol + 3) / 4 : 65536);
   switch ((g.nz + 63) >> 6) {
-    case 1: hipLaunchKernelGGL(esdf_z_small_kernel<1>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx); break;
-    case 2: hipLaunchKernelGGL(esdf_z_small_kernel<2>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx); break;
-    case 3: hipLaunchKernelGGL(esdf_z_small_kernel<3>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx); break;
-    case 4: hipLaunchKernelGGL(esdf_z_small_kernel<4>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx); break;
-    case 5: hipLaunchKernelGGL(esdf_z_small_kernel<5>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx); break;
-    case 6: hipLaunchKernelGGL(esdf_z_small_kernel<6>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx); break;
-    case 7: hipLaunchKernelGGL(esdf_z_small_kernel<7>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx); break;
-    case 8: hipLaunchKernelGGL(esdf_z_small_kernel<8>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx); break;
-    default: hipLaunchKernelGGL(esdf_z_kernel, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, colany, cnt + g.nx);
+    case 1: hipLaunchKernelGGL(esdf_z_small_kernel<1>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx); break;
+    case 2: hipLaunchKernelGGL(esdf_z_small_kernel<2>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx); break;
+    case 3: hipLaunchKernelGGL(esdf_z_small_kernel<3>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx); break;
+    case 4: hipLaunchKernelGGL(esdf_z_small_kernel<4>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx); break;
+    case 5: hipLaunchKernelGGL(esdf_z_small_kernel<5>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx); break;
+    case 6: hipLaunchKernelGGL(esdf_z_small_kernel<6>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx); break;
+    case 7: hipLaunchKernelGGL(esdf_z_small_kernel<7>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx); break;
+    case 8: hipLaunchKernelGGL(esdf_z_small_kernel<8>, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx); break;
+    default: hipLaunchKernelGGL(esdf_z_kernel, dim3(zblocks), dim3(256), 0, stream, g, occ, tmp1, z16, colany, cnt + g.nx);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -868,9 +1086,6 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
     if (e != hipSuccess) return e;
   }
   const int nyz = g.ny * g.nz;
-#ifndef GTOP_ESDF_VEC
-#define GTOP_ESDF_VEC 4
-#endif
   const int V = (GTOP_ESDF_VEC == 4 && g.nz % 4 == 0) ? 4 : 1;   // voxels per lane (16-byte loads need nz % 4 == 0)
   const int nl = nyz / V;
   const unsigned yblocks = 8u * (unsigned)((g.nx + 7) / 8) * (unsigned)((nl + 255) / 256);
@@ -883,15 +1098,20 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
     return 8u * (unsigned)((g.nx + kXB - 1) / kXB) * (unsigned)((per_xcd + block - 1) / block);
   };
   const unsigned xblocks = x_blocks(nl, 256);
-#ifndef GTOP_ESDF_X16
-#define GTOP_ESDF_X16 1
-#endif
   const bool x16 = GTOP_ESDF_X16 && V == 4 && nyz % 8 == 0;   // the packed 16-bit x sweep (8 voxels per lane)
   uint16_t *y16 = x16 ? f16 : (uint16_t *)nullptr;
 #define GTOP_Y_LAUNCH(VV, LL)                                                                                       \
   hipLaunchKernelGGL((esdf_y_kernel<VV, LL>), dim3(yblocks), dim3(256), 0, stream, g, (const int *)tmp1, tmp2, y16, \
                      (const int *)cols, (const int *)rank, (const int *)cnt, (const uint8_t *)colany, cnt)
-  if (V == 4) {
+  if (y16k) {
+    const unsigned y16blocks = 8u * (unsigned)((g.nx + 7) / 8) * (unsigned)((nyz / 8 + 255) / 256);
+    if (ylocal)
+      hipLaunchKernelGGL(esdf_y16_kernel<true>, dim3(y16blocks), dim3(256), 0, stream, g, (const uint16_t *)z16, (const int *)tmp1,
+                         tmp2, y16, (const int *)cols, (const int *)rank, (const int *)cnt, (const uint8_t *)colany, cnt);
+    else
+      hipLaunchKernelGGL(esdf_y16_kernel<false>, dim3(y16blocks), dim3(256), 0, stream, g, (const uint16_t *)z16, (const int *)tmp1,
+                         tmp2, y16, (const int *)cols, (const int *)rank, (const int *)cnt, (const uint8_t *)colany, cnt);
+  } else if (V == 4) {
     if (ylocal) GTOP_Y_LAUNCH(4, true);
     else GTOP_Y_LAUNCH(4, false);
   } else {
