@@ -33,8 +33,8 @@ struct gtop_ctx {
   float *sdf32 = nullptr;
   // The fp32 copy of a rebuilt field.  gtop_update_sdf_map (host points, synchronous) defers it to the first fp32
   // evaluation unless one has been seen on this context (`fp32_in_use`, sticky), because the copy is a third of the
-  // build's writes; gtop_update_sdf_map_device (asynchronous, capturable into a hipGraph) always enqueues it behind
-  // the build on the same stream, so that a REPLAY of the captured rebuild — which never passes through this host
+  // build's writes; gtop_update_sdf_map_device (asynchronous, capturable into a hipGraph) always has the last sweep
+  // write it beside the fp64 field, so that a REPLAY of the captured rebuild — which never passes through this host
   // code again — leaves both precisions current.
   bool sdf32_stale = false;
   bool fp32_in_use = false;
@@ -357,13 +357,11 @@ static int update_sdf_map_on_stream(gtop_ctx *c, const double *d_pts, int npts, 
   // writes every voxel (10000 where the line holds no obstacle, as the reset would have left it)
   HIPCHK(c, gtop_launch_esdf_reset(c->occ, nullptr, nvox, s));
   HIPCHK(c, gtop_launch_esdf_mark(g, d_pts, npts, c->occ, s));         // setOccupancy
-  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, nullptr, s));   // updateESDF3d
-  if (c->sdf32 && (convert_now || c->fp32_in_use)) {
-    HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, s));   // device-side: holds for graph replays too
-    c->sdf32_stale = false;
-  } else {
-    c->sdf32_stale = true;   // converted by the first fp32 evaluation (host-synchronous caller only, see gtop_ctx)
-  }
+  // the fp32 copy rides in the x sweep's stores (device-side: holds for graph replays too) when it is wanted now;
+  // otherwise the first fp32 evaluation converts (host-synchronous caller only, see gtop_ctx)
+  float *const copy32 = (c->sdf32 && (convert_now || c->fp32_in_use)) ? c->sdf32 : nullptr;
+  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, copy32, s));   // updateESDF3d
+  c->sdf32_stale = c->sdf32 && !copy32;
   return GTOP_OK;
 }
 

@@ -66,6 +66,9 @@ struct Member {
   gtop_ctx *ctx = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;     // this member's slice (and its outgoing copies) is complete
+  hipEvent_t ready = nullptr;    // everything enqueued so far that may still read its gathered buffers has run
+  double *pts = nullptr;         // obstacle points of the last map update
+  size_t pts_cap = 0;            // (doubles)
   int first = 0, count = 0;      // its slice of the batch
   double *x = nullptr, *Df = nullptr, *T = nullptr, *cost = nullptr, *grad = nullptr;   // slice buffers, `per` rows
   double *cost_all = nullptr, *grad_all = nullptr;                                      // gathered: n * per rows
@@ -131,9 +134,17 @@ int all_gather(gtop_group *g, bool grads) {
       return gfail(g, GTOP_ERR_HIP, std::string("ncclAllGather: ") + g->rccl.GetErrorString(r != ncclSuccess ? r : r2));
     return GTOP_OK;
   }
+  // a sender writes into the other members' gathered buffers: not before whatever those members had enqueued on
+  // their own streams (a consumer of the previous gather, say) has run
+  for (Member &mb : g->mem) {
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipEventRecord(mb.ready, mb.stream));
+  }
   for (int i = 0; i < n; ++i) {
     Member &src = g->mem[i];
     GHIP(g, hipSetDevice(src.device));
+    for (int j = 0; j < n; ++j)
+      if (j != i) GHIP(g, hipStreamWaitEvent(src.stream, g->mem[j].ready, 0));
     for (int j = 0; j < n; ++j) {
       Member &dst = g->mem[j];
       GHIP(g, hipMemcpyPeerAsync(dst.cost_all + src.first, dst.device, src.cost, src.device,
@@ -180,6 +191,7 @@ int gtop_group_create(gtop_group **out, const int *devices, int n_devices) {
     if (rc == GTOP_OK && hipSetDevice(mb.device) != hipSuccess) rc = GTOP_ERR_HIP;
     if (rc == GTOP_OK && hipStreamCreateWithFlags(&mb.stream, hipStreamNonBlocking) != hipSuccess) rc = GTOP_ERR_HIP;
     if (rc == GTOP_OK && hipEventCreateWithFlags(&mb.done, hipEventDisableTiming) != hipSuccess) rc = GTOP_ERR_HIP;
+    if (rc == GTOP_OK && hipEventCreateWithFlags(&mb.ready, hipEventDisableTiming) != hipSuccess) rc = GTOP_ERR_HIP;
     if (rc != GTOP_OK) {
       gtop_group_destroy(g);
       (void)hipGetLastError();   // (the runtime's error of the failed call must not surface at somebody's next launch)
@@ -236,7 +248,9 @@ int gtop_group_destroy(gtop_group *g) {
     if (!mb.ctx) continue;   // (a member whose creation failed: its device ordinal may not even exist)
     if (mb.comm && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(mb.comm);
     free_slices(mb);
+    if (mb.pts) (void)hipFree(mb.pts);
     if (mb.done) (void)hipEventDestroy(mb.done);
+    if (mb.ready) (void)hipEventDestroy(mb.ready);
     if (mb.stream) (void)hipStreamDestroy(mb.stream);
     if (mb.ctx) (void)gtop_destroy(mb.ctx);
   }
@@ -265,8 +279,23 @@ int gtop_group_init_sdf_map(gtop_group *g, const double map_size[3], const doubl
 
 int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts) {
   if (!g) return GTOP_ERR_INVALID;
-  for (Member &mb : g->mem) GCTX(g, mb, gtop_update_sdf_map(mb.ctx, pts, npts));   // replicated: built on every device
-  return GTOP_OK;
+  if (npts < 0 || (npts > 0 && !pts)) return gfail(g, GTOP_ERR_INVALID, "bad obstacle list");
+  // replicated: every device builds the field from the same points, all of them at the same time (the upload and the
+  // build are enqueued on each member's stream before any is waited for)
+  const size_t need = (size_t)npts * 3;
+  for (Member &mb : g->mem) {
+    GHIP(g, hipSetDevice(mb.device));
+    if (need > mb.pts_cap) {
+      if (mb.pts) GHIP(g, hipFree(mb.pts));
+      mb.pts = nullptr;
+      mb.pts_cap = 0;
+      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.pts), need * sizeof(double)));
+      mb.pts_cap = need;
+    }
+    if (need) GHIP(g, hipMemcpyAsync(mb.pts, pts, need * sizeof(double), hipMemcpyHostToDevice, mb.stream));
+    GCTX(g, mb, gtop_update_sdf_map_device(mb.ctx, mb.pts, npts, mb.stream));
+  }
+  return sync_all(g);
 }
 
 int gtop_group_set_sdf(gtop_group *g, const double *dist_host, int nx, int ny, int nz, const double origin[3],
@@ -294,7 +323,7 @@ int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_ti
     // slices padded to `per` rows (RCCL's all-gather sends equal counts); the padding is never read as a result
     GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.x), (size_t)per * nvar * sizeof(double)));
     GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.Df), (size_t)per * 18 * sizeof(double)));
-    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.T), (size_t)(time_stride ? per * m : m) * sizeof(double)));
+    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.T), (time_stride ? (size_t)per * m : (size_t)m) * sizeof(double)));
     GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.cost), (size_t)per * sizeof(double)));
     GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.grad), (size_t)per * nvar * sizeof(double)));
     GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.cost_all), (size_t)n * per * sizeof(double)));

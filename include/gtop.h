@@ -108,9 +108,9 @@ int gtop_update_sdf_map(gtop_ctx *ctx, const double *obstacle_pts, int npts);
 /* The same with the obstacle points (npts x 3 doubles, xyz-contiguous) already in
  * HBM: launches on `hip_stream` and returns without synchronising — the build is
  * five kernels, 0.08 ms for a 200^3 map, against 0.6 ms of PCIe for the points of
- * the host form.  The fp32 copy of the field is refreshed by the first fp32
- * evaluation after it (on that evaluation's stream: order the two yourself if
- * they differ). */
+ * the host form.  The fp32 copy of the field (if the context holds one) is
+ * written by the last sweep beside the fp64 field, so the call can be captured
+ * into a hipGraph and replayed with fp32 evaluations behind it. */
 int gtop_update_sdf_map_device(gtop_ctx *ctx, const void *d_obstacle_pts, int npts, void *hip_stream);
 /* Copy the resident fp64 distance field back to the host (nx*ny*nz doubles). */
 int gtop_get_sdf(gtop_ctx *ctx, double *dist_host, int grid_out[3]);

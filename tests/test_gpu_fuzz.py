@@ -1,0 +1,124 @@
+"""Randomised differential test: the HIP path against the oracle on seeded draws of EVERYTHING the boundary takes —
+map shape / resolution / origin / obstacle density, batch size, segment count (every body of the launch rule: one or
+two trajectories per wavefront, two wavefronts per trajectory, the chunked body past 12 segments), shared or
+per-trajectory segment times, zero or random boundary velocity / acceleration, the parameter set (weights incl. 0,
+alpha / r / d0, step, the dyn-feasibility block), rows that leave the map, segments short enough to lose samples
+(`t += dt` replay, src/grad_traj_optimizer.cpp:345-409), both entry points (host arrays, resident tensors).
+Every draw is reproducible from its seed; the tolerance is BASELINE.json's 1e-5 relative (fp64)."""
+import numpy as np
+import pytest
+
+from grad_traj_optimization_amd import problem
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+TOL64, TOL32 = 1e-5, 2e-4
+
+
+def _draw(seed):
+    rng = np.random.default_rng(10_000 + seed)
+    res = float(rng.choice([0.1, 0.2, 0.25, 0.4]))
+    grid = tuple(int(v) for v in rng.integers(12, 72, size=3))
+    if seed % 7 == 0:
+        grid = (grid[0], grid[1], int(rng.integers(3, 9)))            # a flat map, as the reference's 200 x 200 x 25
+    occ = (rng.random(grid) < rng.choice([0.002, 0.02, 0.08])).astype(np.uint8)
+    occ[tuple(int(v) for v in rng.integers(0, grid))] = 1              # never an empty map
+    origin = np.array([-grid[0] * res / 2, -grid[1] * res / 2, 0.0]) + rng.uniform(-3, 3, 3) * (seed % 3 == 0)
+    mp = problem.MapSpec(grid, res, origin, occ)
+    m = int(rng.choice([2, 3, 4, 5, 6, 6, 6, 7, 9, 10, 12, 13, 17, 25, 40]))
+    B = int(rng.choice([1, 2, 3, 17, 64, 65, 130, 257]))
+    extent = float(min(mp.map_size))
+    margin = min(1.0, extent / 4)
+    step = (0.15 * extent / 2, 0.4 * extent / 2)
+    b = problem.make_trajectories(B, m, mp, seed=seed, step_len=step, margin=margin,
+                                  noise=float(rng.choice([0.0, 0.05, 0.3])),
+                                  boundary="random" if rng.random() < 0.5 else None)
+    x, T = b.x.copy(), b.T.copy()
+    if rng.random() < 0.4:                                             # rows that leave the map, on any axis
+        rows = rng.integers(0, B, size=max(1, B // 8))
+        x[rows, rng.integers(0, x.shape[1], size=rows.size)] += rng.choice([-1.0, 1.0]) * 2.0 * extent
+    short = rng.random() < 0.4                                         # segments that lose samples (applied below)
+    short_rows = rng.integers(0, B, size=max(1, B // 8))
+    short_seg = rng.integers(0, m, size=short_rows.size)
+    short_T = rng.choice([0.03, 0.02, 0.0009, 0.031, 0.3], size=short_rows.size)
+    shared_T = rng.random() < 0.25
+    kw = dict(ws=float(rng.choice([1.0, 0.0, 1e-3, 20.0])), wc=float(rng.choice([5.0, 5.0, 1.0, 50.0, 0.0, 5e-5])),
+              alpha=float(rng.choice([10.0, 1.0, 100.0])), r=float(rng.choice([0.5, 0.2, 1.0])),
+              d0=float(rng.choice([0.8, 0.3, 2.0])), step=int(rng.choice([2, 2, 2, 1])))
+    if kw["ws"] == 0.0 and abs(kw["wc"]) < 1e-4:
+        kw["ws"] = 1.0                                                 # (a cost of exactly 1e-3 + nothing: keep it a test of something)
+    if rng.random() < 0.3:
+        kw.update(enable_dyn=1, alpha_v=float(rng.choice([1.0, 5.0])), r_v=4.0, v0=float(rng.choice([1.0, 2.5])),
+                  alpha_a=float(rng.choice([1.0, 3.0])), r_a=15.0, a0=float(rng.choice([1.0, 3.5])))
+    if short and not kw.get("enable_dyn"):      # (a metre in 20 ms is 50 m/s: exp(v^2 / r_v) overflows in the reference too)
+        T[short_rows, short_seg] = short_T
+    if shared_T:
+        T = T[0].copy()
+    return mp, problem.Batch(b.waypoints, T, b.Df, x, m), kw, shared_T
+
+
+def _reference(oracle_mod, mp, b, kw):
+    sdf = oracle_mod.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+    sdf.build_from_occupancy(mp.occupancy)
+    return oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params(**kw), nthreads=8)[:2], sdf
+
+
+def _compare(c, g, c_ref, g_ref, tol, what):
+    assert np.isfinite(c_ref).all() and np.isfinite(g_ref).all(), "the draw itself is degenerate"
+    assert np.isfinite(c).all() and np.isfinite(g).all(), what
+    rc, rg = scenes.rel_err(c, g, c_ref, g_ref)
+    assert rc <= tol and rg <= tol, (what, rc, rg)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_draw_matches_the_oracle(gtop, oracle_mod, seed):
+    import torch
+    mp, b, kw, shared_T = _draw(seed)
+    (c_ref, g_ref), sdf = _reference(oracle_mod, mp, b, kw)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    assert tuple(ctx.grid) == tuple(mp.grid) == sdf.grid
+    ctx.update_sdf_map(mp.obstacle_points())
+    assert np.array_equal(ctx.get_sdf().reshape(-1), sdf.dist)         # the field the lookups read: bit for bit
+    ctx.set_params(**kw)
+    # host entry point (gtop_set_problem + gtop_eval_batch)
+    ctx.set_problem(b.T, b.Df)
+    c, g = ctx.eval_batch(b.x)
+    _compare(c, g, c_ref, g_ref, TOL64, ("host", seed, b.m, len(b.x), kw))
+    # resident entry point, same bits
+    dev = torch.device("cuda:0")
+    xd, Dfd, Td = (torch.tensor(a, dtype=torch.float64, device=dev) for a in (b.x, b.Df.reshape(-1, 18), b.T))
+    cd, gd = ctx.eval_device(xd, Dfd, Td)
+    torch.cuda.synchronize()
+    assert np.array_equal(cd.cpu().numpy(), c) and np.array_equal(gd.cpu().numpy(), g)
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_random_draw_fp32(gtop, oracle_mod, seed):
+    """The fp32 bodies on the draws whose rows stay ordinary (no out-of-map excursions of two map widths, no segment
+    of under a millisecond: beyond fp32's digits, tested with their own bounds in test_gpu_wave.py)."""
+    import torch
+    mp, b, kw, shared_T = _draw(seed)
+    m = b.m
+    bb = problem.make_trajectories(len(b.x), m, mp, seed=seed, step_len=(0.15 * min(mp.map_size) / 2, 0.4 * min(mp.map_size) / 2),
+                                   margin=min(1.0, float(min(mp.map_size)) / 4), boundary="random" if seed % 2 else None)
+    T = bb.T[0].copy() if shared_T else bb.T
+    kw = {k: v for k, v in kw.items() if k not in ("alpha", "r", "d0")}   # (alpha = 100 with r = 0.2 amplifies fp32's position rounding 5x)
+    bb = problem.Batch(bb.waypoints, T, bb.Df, bb.x, m)
+    (c_ref, g_ref), sdf = _reference(oracle_mod, mp, bb, kw)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    ctx.set_params(**kw)
+    dev = torch.device("cuda:0")
+    xd, Dfd, Td = (torch.tensor(a, dtype=torch.float32, device=dev) for a in (bb.x, bb.Df.reshape(-1, 18), bb.T))
+    cd, gd = ctx.eval_device(xd, Dfd, Td)
+    torch.cuda.synchronize()
+    # (dyn: exp((v^2 - v0^2) / 4) turns the velocity's fp32 rounding into v / 2 times as much: rows of 1e13 are v ~ 11 m/s)
+    tol = 5e-3 if kw.get("enable_dyn") else TOL32
+    c, g = cd.double().cpu().numpy(), gd.double().cpu().numpy()
+    fits = (c_ref < 1e30) & (np.abs(g_ref).max(axis=1) < 1e30)          # rows past fp32's range (3.4e38) may come back inf
+    assert fits.mean() > 0.9 and (~np.isfinite(c[~fits]) | (c[~fits] > 1e30)).all()
+    _compare(c[fits], g[fits], c_ref[fits], g_ref[fits], tol, ("f32", seed, m, len(bb.x), kw))
+    ctx.close()

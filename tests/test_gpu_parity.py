@@ -48,6 +48,9 @@ def test_esdf_bit_exact(scene):
     ((70, 130, 68), "random"),       # two 64-voxel chunks per column, several ballots per slab's column flags
     ((6, 10, 320), "random"),        # five chunks per column: the scalar-mask z sweep's upper variants
     ((4, 6, 520), "random"),         # columns past 512 voxels: the LDS-mask z sweep
+    ((8, 12, 320), "floor"),         # obstacles at z = 0 only: z distances past 255 voxels saturate the 16-bit copy the
+    ((4, 6, 520), "floor"),          # packed y sweep reads -> its 32-bit walk (scalar-mask and LDS-mask z sweeps)
+    ((40, 300, 16), "one_end"),      # the packed y sweep's own saturation: free space wider than 255 voxels along y
 ])
 def test_esdf_grid_shapes_bit_exact(gtop, grid, kind):
     """The exact EDT on grid shapes that pick each sweep variant, against scipy's exact transform."""
@@ -66,6 +69,9 @@ def test_esdf_grid_shapes_bit_exact(gtop, grid, kind):
         occ[1, 2, 3] = 1
     elif kind == "single":
         occ[nx // 2, ny // 3, nz // 2] = 1
+    elif kind == "floor":
+        occ[:, :, 0][rng.random((nx, ny)) < 0.3] = 1
+        occ[0, 0, 0] = 1
     elif kind == "corner":
         occ[:6, :6, :][rng.random((6, 6, nz)) < 0.3] = 1
         occ[0, 0, 0] = 1
