@@ -912,6 +912,9 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
           for (int i = 0; i < li + j * LPS; ++i) t += dtq;
           awj = (t < T) ? pen_alpha * (wc * dtq) : (R)0;
           sdt = (t < T) ? dtq : (R)0;
+          // a sample past the loop bound (:353) is not evaluated by the reference; here it is, with weight 0 — at the
+          // first sample's time rather than on the extrapolated polynomial, where an exp could overflow into 0 * inf
+          t = (t < T) ? t : (R)1e-3;
         }
       }
     };
@@ -933,7 +936,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
 #pragma unroll
           for (int j = 0; j < SPL; ++j) {
             for (; i < li + j * LPS; ++i) t += dtq;
-            ts[j] = t;
+            ts[j] = (t < T) ? t : (R)1e-3;   // (past the loop bound: weight 0, evaluated at the first sample's time; see sample_time)
             aw[j] = (t < T) ? pen_alpha * (wc * dtq) : (R)0;
             sdts[j] = (t < T) ? dtq : (R)0;
           }

@@ -64,13 +64,17 @@ def _reference(oracle_mod, mp, b, kw):
 
 
 def _compare(c, g, c_ref, g_ref, tol, what):
-    assert np.isfinite(c_ref).all() and np.isfinite(g_ref).all(), "the draw itself is degenerate"
+    # a row whose exp overflows fp64 in the reference (dyn block, a segment of a few ms) must overflow here too
+    over = ~np.isfinite(c_ref) | ~np.isfinite(g_ref).all(axis=1)
+    assert over.mean() < 0.1, "the draw itself is degenerate"
+    assert not np.isfinite(c[~np.isfinite(c_ref)]).any(), what
+    c, g, c_ref, g_ref = c[~over], g[~over], c_ref[~over], g_ref[~over]
     assert np.isfinite(c).all() and np.isfinite(g).all(), what
     rc, rg = scenes.rel_err(c, g, c_ref, g_ref)
     assert rc <= tol and rg <= tol, (what, rc, rg)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(160))
 def test_random_draw_matches_the_oracle(gtop, oracle_mod, seed):
     import torch
     mp, b, kw, shared_T = _draw(seed)
@@ -90,11 +94,11 @@ def test_random_draw_matches_the_oracle(gtop, oracle_mod, seed):
     xd, Dfd, Td = (torch.tensor(a, dtype=torch.float64, device=dev) for a in (b.x, b.Df.reshape(-1, 18), b.T))
     cd, gd = ctx.eval_device(xd, Dfd, Td)
     torch.cuda.synchronize()
-    assert np.array_equal(cd.cpu().numpy(), c) and np.array_equal(gd.cpu().numpy(), g)
+    assert np.array_equal(cd.cpu().numpy(), c, equal_nan=True) and np.array_equal(gd.cpu().numpy(), g, equal_nan=True)
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(100, 116))
+@pytest.mark.parametrize("seed", range(1000, 1040))
 def test_random_draw_fp32(gtop, oracle_mod, seed):
     """The fp32 bodies on the draws whose rows stay ordinary (no out-of-map excursions of two map widths, no segment
     of under a millisecond: beyond fp32's digits, tested with their own bounds in test_gpu_wave.py)."""
@@ -116,7 +120,8 @@ def test_random_draw_fp32(gtop, oracle_mod, seed):
     cd, gd = ctx.eval_device(xd, Dfd, Td)
     torch.cuda.synchronize()
     # (dyn: exp((v^2 - v0^2) / 4) turns the velocity's fp32 rounding into v / 2 times as much: rows of 1e13 are v ~ 11 m/s)
-    tol = 5e-3 if kw.get("enable_dyn") else TOL32
+    # (past 12 segments the chunked body's longer fp32 sums: 2.8e-4 seen at 17 segments)
+    tol = 5e-3 if kw.get("enable_dyn") else (TOL32 if m <= 12 else 1e-3)
     c, g = cd.double().cpu().numpy(), gd.double().cpu().numpy()
     fits = (c_ref < 1e30) & (np.abs(g_ref).max(axis=1) < 1e30)          # rows past fp32's range (3.4e38) may come back inf
     assert fits.mean() > 0.9 and (~np.isfinite(c[~fits]) | (c[~fits] > 1e30)).all()

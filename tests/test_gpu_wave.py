@@ -175,3 +175,32 @@ np.savez(sys.argv[1], **out)
         res[name] = np.load(f)
     for k in res["asm"].files:
         assert np.array_equal(res["asm"][k], res["noasm"][k]), k
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("spl", [3, 6])
+def test_samples_past_the_loop_bound_cannot_overflow_into_the_sums(scene, oracle_mod, dtype, spl):
+    """A 20 ms segment has 20 samples (`t += dt` up to T, src/grad_traj_optimizer.cpp:353); the lanes of the other ten
+    evaluate too, with weight 0.  With the dyn block on and r_v just large enough for the reference's own samples
+    to stay inside the exponent range, the polynomial EXTRAPOLATED past T overflows exp: those lanes are evaluated
+    at the first sample's time instead, so that no 0 * inf reaches the sums."""
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(6, 4, mp, seed=77, boundary="random")
+    T = b.T.copy()
+    T[:, 1] = 0.02
+    limit = 700.0 if dtype == "f64" else 70.0        # (exp's argument range, with a margin for the gradient's factors)
+    kw = dict(enable_dyn=1, alpha_v=1.0, v0=1.0, alpha_a=0.0, r_a=1e6, a0=1.0)
+    lo, hi = 1e-3, 1e3                                # smallest r_v for which the reference stays finite and in range
+    for _ in range(40):
+        mid = np.sqrt(lo * hi)
+        c_try = oracle_mod.eval_batch(T, b.Df, b.x, sdf, oracle_mod.make_params(r_v=mid, **kw))[0]
+        ok = np.isfinite(c_try).all() and c_try.max() < np.exp(limit)
+        lo, hi = (lo, mid) if ok else (mid, hi)
+    kw["r_v"] = float(hi * 1.02)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(T, b.Df, b.x, sdf, oracle_mod.make_params(**kw))
+    assert np.isfinite(c_ref).all() and c_ref.max() > np.exp(0.8 * limit)      # live samples close to the limit
+    c, g = _run(ctx, problem.Batch(b.waypoints, T, b.Df, b.x, 4), spl, dtype, **kw)
+    assert np.isfinite(c).all() and np.isfinite(g).all()
+    rc, rg = scenes.rel_err(c, g, c_ref, g_ref)
+    tol = TOL64 if dtype == "f64" else 2e-2           # (fp32: exp(80) turns the velocity's rounding into 1e-3 and more)
+    assert rc <= tol and rg <= tol, (rc, rg)
