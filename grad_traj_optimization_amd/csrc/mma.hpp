@@ -109,7 +109,12 @@ inline MmaResult mma_minimize(unsigned n, mma_objective f, void *f_data, const d
   res.nevals++;
   res.minf = fcur;
   std::memcpy(xcur.data(), x, sizeof(double) * n);
-  if (!std::isfinite(fcur)) { res.code = MMA_FAILURE; return res; }
+  // A non-finite value is not an exit, as in NLopt's mma.c (and in the device loop, gtop_device_common.h): +inf from an
+  // exp that overflowed on a long step is a rejected step — rho grows and the next one is shorter; NaN is rejected
+  // with rho unchanged, so the same point is evaluated until a limit ends the run.  Only a NaN with NO limit set
+  // could never end: that alone is reported as a failure.
+  auto hopeless = [&](double f) { return std::isnan(f) && opt.maxeval <= 0 && opt.maxtime <= 0; };
+  if (hopeless(fcur)) { res.code = MMA_FAILURE; return res; }
   int k = 0, ret = MMA_SUCCESS;
   const double kRhoMin = 1e-5;
 
@@ -124,7 +129,7 @@ inline MmaResult mma_minimize(unsigned n, mma_objective f, void *f_data, const d
       mma_separable_step(n, x, dfdx.data(), sigma.data(), rho, lb, ub, res.minf, xcur.data(), &gval, &wval);
       fcur = f(n, xcur.data(), dfdx_cur.data(), f_data);
       res.nevals++;
-      if (!std::isfinite(fcur)) { res.code = MMA_FAILURE; return res; }
+      if (hopeless(fcur)) { res.code = MMA_FAILURE; return res; }
       const bool inner_done = gval >= fcur;
       if (fcur < res.minf) {   // accept: new base point
         res.minf = fcur;

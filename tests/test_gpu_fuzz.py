@@ -127,3 +127,39 @@ def test_random_draw_fp32(gtop, oracle_mod, seed):
     assert fits.mean() > 0.9 and (~np.isfinite(c[~fits]) | (c[~fits] > 1e30)).all()
     _compare(c[fits], g[fits], c_ref[fits], g_ref[fits], tol, ("f32", seed, m, len(bb.x), kw))
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(2000, 2040))
+def test_random_draw_optimizer(gtop, oracle_mod, seed):
+    """The batched device optimizer on random draws against the serial CCSA-MMA of csrc/mma.hpp driven by the oracle
+    callback (oracle/cpu_optimizer.cpp): same best point, best cost and evaluation count per trajectory — every body
+    of the loop (up to 6, 7..12 and more segments, the dyn block), the three launch forms, random bounds."""
+    mp, b, kw, shared_T = _draw(seed)
+    rng = np.random.default_rng(seed)
+    B = min(len(b.x), 24)
+    T = np.broadcast_to(b.T, (len(b.x), b.m))[:B].copy()
+    T = np.maximum(T, 0.05)                     # (no sample-losing segments: their jerk term of 1e18 leaves nothing to compare)
+    Df, x0 = b.Df[:B], np.clip(b.x[:B], -1e3, 1e3)
+    if kw["ws"] == 0.0:
+        kw["ws"] = 1.0
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints[:B], bos=float(rng.choice([0.5, 3.0])),
+                                             vos=float(rng.choice([2.0, 8.0])), aos=float(rng.choice([3.0, 10.0])))
+    evals = int(rng.integers(2, 30))
+    sdf = oracle_mod.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+    sdf.build_from_occupancy(mp.occupancy)
+    x_ref, c_ref, n_ref, _ = oracle_mod.optimize_batch(T, Df, x0, lb, ub, sdf, oracle_mod.make_params(**kw), evals, nthreads=8)
+    ok = np.isfinite(c_ref)                      # (a start that overflows is MMA_FAILURE in both; nothing to compare)
+    assert ok.mean() > 0.5
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    ctx.set_params(**kw)
+    ctx.set_problem(T, Df)
+    ctx.set_optimizer_fusion(int(rng.choice([2, 2, 1, 0])))
+    xs, costs, nev, code = ctx.optimize_batch_ex(x0, lb, ub, evals)
+    ctx.close()
+    what = (seed, b.m, B, evals, kw)
+    assert np.array_equal(nev[ok], n_ref[ok]), what
+    assert np.all(np.abs(costs[ok] - c_ref[ok]) <= 1e-6 * np.abs(c_ref[ok])), what
+    assert np.max(np.abs(xs[ok] - x_ref[ok])) <= 1e-6 * max(1.0, np.max(np.abs(x_ref[ok]))), what
+    assert np.all(xs >= lb - 1e-12) and np.all(xs <= ub + 1e-12)
