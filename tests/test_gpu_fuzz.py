@@ -163,3 +163,111 @@ def test_random_draw_optimizer(gtop, oracle_mod, seed):
     assert np.all(np.abs(costs[ok] - c_ref[ok]) <= 1e-6 * np.abs(c_ref[ok])), what
     assert np.max(np.abs(xs[ok] - x_ref[ok])) <= 1e-6 * max(1.0, np.max(np.abs(x_ref[ok]))), what
     assert np.all(xs >= lb - 1e-12) and np.all(xs <= ub + 1e-12)
+
+
+@pytest.mark.parametrize("seed", range(3000, 3020))
+def test_random_draw_queries_and_post_processing(gtop, oracle_mod, seed):
+    """The rows either side of the callback on the same random maps and batches: setPath's times and derivative rows
+    (bit for bit), the polynomial coefficients / statistics / getTraj points of a random x, and the static + moving
+    box distance queries (fine and coarse), each against the oracle's restatement."""
+    mp, b, kw, shared_T = _draw(seed)
+    rng = np.random.default_rng(seed)
+    sdf = oracle_mod.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+    sdf.build_from_occupancy(mp.occupancy)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    B, m = min(len(b.x), 20), b.m
+    wp = b.waypoints[:B]
+    # f3: setPath on the device
+    mean_v, init_time = float(rng.choice([1.8, 0.7, 3.0])), float(rng.choice([0.3, 0.0, 1.0]))
+    x0 = ctx.set_paths(wp, mean_v=mean_v, init_time=init_time)
+    T, Df = ctx.get_problem()
+    for i in range(B):
+        assert np.array_equal(T[i], oracle_mod.segment_time(wp[i], mean_v, init_time))
+        Df_ref, Dp_ref = oracle_mod.initial_d(wp[i])
+        assert np.array_equal(Df[i], Df_ref) and np.array_equal(x0[i], Dp_ref.reshape(-1))
+    # f4: coefficients, statistics, sampled points of a perturbed x with the draw's boundary rows
+    x = x0 + rng.normal(0, 0.3, x0.shape)
+    T = np.maximum(T, 0.05)
+    ctx.set_problem(T, b.Df[:B])
+    dt = float(rng.choice([0.01, 0.05, 0.003]))
+    coeff, stats = ctx.trajectory_stats(x, dt_sample=dt)
+    cap = int(rng.choice([64, 1000, 4096]))
+    stats2, samples = ctx.trajectory_samples(x, dt_sample=dt, max_samples=cap)
+    assert np.array_equal(stats, stats2)
+    for i in range(B):
+        c_ref = oracle_mod.coefficients(T[i], b.Df[i], x[i])
+        assert np.allclose(coeff[i], c_ref, rtol=1e-9, atol=1e-9 * np.abs(c_ref).max())
+        s_ref = oracle_mod.traj_stats(coeff[i], T[i], dt)
+        assert stats[i, 8] == s_ref[8] and stats[i, 0] == s_ref[0]
+        assert np.allclose(stats[i, 1:8], s_ref[1:8], rtol=1e-8, atol=1e-10)
+        n_ref, pts_ref = oracle_mod.traj_samples(coeff[i], T[i], dt, max_samples=cap)
+        k = min(n_ref, cap)
+        scale = max(1.0, np.abs(pts_ref).max()) if k else 1.0
+        assert stats[i, 8] == n_ref and np.allclose(samples[i, :k], pts_ref, rtol=1e-9, atol=1e-9 * scale)
+        assert np.all(samples[i, k:] == 0.0)
+    # f4: distance queries
+    nbox, nq = int(rng.choice([0, 1, 9, 70])), int(rng.choice([1, 63, 64, 65, 777]))
+    p0 = rng.uniform(mp.origin, mp.origin + mp.map_size, size=(nbox, 3))
+    vel = rng.uniform(-1.0, 1.0, size=(nbox, 3))
+    scale = rng.uniform(0.3, 1.5, size=(nbox, 3))
+    pos = rng.uniform(mp.origin - 0.3, mp.origin + mp.map_size + 0.3, size=(nq, 3))
+    time = rng.uniform(0.0, 3.0, size=nq)
+    time[::3] = -1.0
+    ctx.set_moving_boxes(p0, vel, scale)
+    d, g = ctx.edt_query(pos, time)
+    d_ref, g_ref = sdf.edt_query(pos, time, p0, vel, scale)
+    assert np.allclose(d, d_ref, rtol=1e-12, atol=1e-12) and np.allclose(g, g_ref, rtol=1e-10, atol=1e-10)
+    assert ((d == -1.0) == (d_ref == -1.0)).all()
+    dc = ctx.edt_coarse_query(pos, time)
+    assert np.allclose(dc, sdf.edt_coarse(pos, time, p0, vel, scale), rtol=1e-13, atol=1e-13)
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(4000, 4040))
+def test_random_esdf_build_is_scipys_exact_transform(gtop, seed):
+    """updateESDF3d on random grid shapes and obstacle patterns — every sweep variant the launcher can pick (packed
+    16-bit or 32-bit, one or four or eight voxels per lane, columns of 1 .. 9 chunks, candidate lists in LDS, jumps
+    over empty slabs, the saturated cases past 255 voxels) — bit for bit scipy's exact Euclidean transform."""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    shape = [int(rng.choice([3, 8, 16, 24, 40, 64, 72, 96])) for _ in range(3)]
+    long_axis = int(rng.integers(0, 3))
+    shape[long_axis] = int(rng.choice([130, 200, 264, 300, 520]))          # one axis long: saturation, many chunks
+    if rng.random() < 0.3:
+        shape = [int(v) for v in rng.integers(2, 50, size=3)]              # small and odd
+    while shape[0] * shape[1] * shape[2] > 3_000_000:
+        shape[int(np.argsort(shape)[1])] //= 2
+    grid = tuple(max(2, v) for v in shape)
+    occ = np.zeros(grid, dtype=np.uint8)
+    kind = rng.choice(["random", "sparse", "one", "slab", "corner", "dense"])
+    if kind == "random":
+        occ[rng.random(grid) < 0.02] = 1
+    elif kind == "sparse":
+        for _ in range(int(rng.integers(1, 6))):
+            occ[tuple(int(v) for v in rng.integers(0, grid))] = 1
+    elif kind == "slab":                                                    # obstacles in a few x slabs only
+        xs = rng.integers(0, grid[0], size=max(1, grid[0] // 20))
+        occ[xs] = (rng.random((len(xs),) + grid[1:]) < 0.05)
+    elif kind == "corner":
+        sub = tuple(slice(0, max(1, g // 8)) for g in grid)
+        occ[sub] = rng.random(occ[sub].shape) < 0.3
+    elif kind == "dense":
+        occ[rng.random(grid) < 0.4] = 1
+    occ[tuple(int(v) for v in rng.integers(0, grid))] = 1
+    res = float(rng.choice([0.2, 0.1, 0.25]))
+    mp = problem.MapSpec(grid, res, np.array([-grid[0] * res / 2, -grid[1] * res / 2, 0.0]), occ)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, res)
+    assert tuple(ctx.grid) == grid
+    ctx.update_sdf_map(mp.obstacle_points())
+    d = ctx.get_sdf()
+    ref = res * ndimage.distance_transform_edt(occ == 0)
+    assert np.array_equal(d, ref), (grid, kind, int((d != ref).sum()))
+    # a second build on the same context with other obstacles: nothing of the first may survive in the workspaces
+    occ2 = np.zeros(grid, dtype=np.uint8)
+    occ2[tuple(int(v) for v in rng.integers(0, grid))] = 1
+    ctx.update_sdf_map(problem.MapSpec(grid, res, mp.origin, occ2).obstacle_points())
+    assert np.array_equal(ctx.get_sdf(), res * ndimage.distance_transform_edt(occ2 == 0)), (grid, kind, "rebuild")
+    ctx.close()
