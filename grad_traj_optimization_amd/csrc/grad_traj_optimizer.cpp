@@ -2,6 +2,7 @@
 // file:line citations are into EpicOne1/grad_traj_optimization.
 #include "grad_traj_optimizer.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 
@@ -289,35 +290,47 @@ void GradTrajBatch::updateSDFMap(const std::vector<Vec3> &obs) {
 }
 
 void GradTrajBatch::setPaths(const std::vector<std::vector<Vec3>> &way_points) {
-  const int B = (int)way_points.size(), npts = B ? (int)way_points[0].size() : 0;
-  bool same = B > 0 && npts >= 3;
-  for (const auto &w : way_points) same = same && (int)w.size() == npts;
-  if (!grp_ || !same) {
+  const int B = (int)way_points.size();
+  bool valid = B > 0;
+  for (const auto &w : way_points) valid = valid && w.size() >= 3;
+  if (!grp_ || !valid) {
     last_status_ = GTOP_ERR_INVALID;
     return;
   }
-  const int m = npts - 1, num_dp = 3 * m - 3;
   B_ = B;
-  m_ = m;
-  path_.assign((size_t)B * npts * 3, 0.0);
-  T_.assign((size_t)B * m, 0.0);
-  Df_.assign((size_t)B * 18, 0.0);
-  x_.assign((size_t)B * 3 * num_dp, 0.0);
+  m_of_.assign(B, 0);
+  path_at_.assign(B, 0);
+  T_at_.assign(B, 0);
+  x_at_.assign(B, 0);
+  size_t np = 0, nt = 0, nx = 0;
   for (int b = 0; b < B; ++b) {
-    double *p = &path_[(size_t)b * npts * 3];
-    for (int i = 0; i < npts; ++i)
+    const int m = (int)way_points[b].size() - 1;
+    m_of_[b] = m;
+    path_at_[b] = np; T_at_[b] = nt; x_at_[b] = nx;
+    np += (size_t)(m + 1) * 3; nt += (size_t)m; nx += 9 * (size_t)(m - 1);
+  }
+  path_.assign(np, 0.0);
+  T_.assign(nt, 0.0);
+  Df_.assign((size_t)B * 18, 0.0);
+  x_.assign(nx, 0.0);
+  for (int b = 0; b < B; ++b) {
+    const int m = m_of_[b], num_dp = 3 * m - 3;
+    double *p = &path_[path_at_[b]], *T = &T_[T_at_[b]], *x = &x_[x_at_[b]];
+    for (int i = 0; i <= m; ++i)
       for (int a = 0; a < 3; ++a) p[i * 3 + a] = way_points[b][i][a];
     for (int i = 0; i < m; ++i) {   // :73-81 (only segment 0 gets init_time: the `i == size()` clause never holds)
       const double dx = p[i * 3] - p[(i + 1) * 3], dy = p[i * 3 + 1] - p[(i + 1) * 3 + 1], dz = p[i * 3 + 2] - p[(i + 1) * 3 + 2];
-      T_[(size_t)b * m + i] = std::sqrt(dx * dx + dy * dy + dz * dz) / cfg_.mean_v + (i == 0 ? cfg_.init_time : 0.0);
+      T[i] = std::sqrt(dx * dx + dy * dy + dz * dz) / cfg_.mean_v + (i == 0 ? cfg_.init_time : 0.0);
     }
     for (int a = 0; a < 3; ++a) {   // getInitialD (src/qp_generator.cpp:407-451): positions only, zero velocity / acceleration
       Df_[(size_t)b * 18 + a * 6 + 0] = p[a];
       Df_[(size_t)b * 18 + a * 6 + 3] = p[m * 3 + a];
-      for (int k = 1; k < m; ++k) x_[(size_t)b * 3 * num_dp + (size_t)a * num_dp + (k - 1) * 3] = p[k * 3 + a];
+      for (int k = 1; k < m; ++k) x[(size_t)a * num_dp + (k - 1) * 3] = p[k * 3 + a];
     }
   }
-  last_status_ = gtop_group_set_problem(grp_, B, m, T_.data(), m, Df_.data());
+  min_cost_.assign(B, 0.0);
+  nevals_.assign(B, 0);
+  last_status_ = GTOP_OK;
 }
 
 bool GradTrajBatch::optimizeTrajectories(int step) {
@@ -330,37 +343,65 @@ bool GradTrajBatch::optimizeTrajectories(int step) {
   p.step = step;
   p.enable_dyn = cfg_.enable_dyn;
   if ((last_status_ = gtop_group_set_params(grp_, &p)) != GTOP_OK) return true;
-  const int npts = m_ + 1;
-  const size_t n = 9 * (size_t)(m_ - 1);
-  std::vector<double> lb((size_t)B_ * n), ub((size_t)B_ * n);
-  gtop_default_bounds(B_, m_, path_.data(), cfg_.bos, cfg_.vos, cfg_.aos, lb.data(), ub.data());   // :151-179
-  (void)npts;
   const double maxtime = step == OPT_FIRST_STEP ? cfg_.time_limit_1 : (step == OPT_SECOND_STEP ? cfg_.time_limit_2 : 0.0);
   const gtop_stop stop = {cfg_.max_evals > 0 ? cfg_.max_evals : (1 << 24), 0.0, 0.0, maxtime};   // :144-148
-  min_cost_.assign(B_, 0.0);
-  nevals_.assign(B_, 0);
-  std::vector<int32_t> nev(B_), code(B_);
-  last_status_ = gtop_group_optimize_batch_ex(grp_, B_, x_.data(), lb.data(), ub.data(), &stop, min_cost_.data(), nev.data(),
-                                              code.data());
-  for (int b = 0; b < B_; ++b) nevals_[b] = nev[b];
+  // one device problem per distinct segment count, in rising order; each is the whole optimisation of its
+  // trajectories in one launch per device (the wall-clock limit is each problem's own, as it is each object's in the
+  // reference)
+  std::vector<int> order(B_);
+  for (int b = 0; b < B_; ++b) order[b] = b;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return m_of_[a] < m_of_[b]; });
+  std::vector<double> T, Df, x, path, lb, ub, cost;
+  std::vector<int32_t> nev, code;
+  for (int lo = 0; lo < B_;) {
+    const int m = m_of_[order[lo]];
+    int hi = lo;
+    while (hi < B_ && m_of_[order[hi]] == m) ++hi;
+    const int nb = hi - lo;
+    const size_t n = 9 * (size_t)(m - 1), np = (size_t)(m + 1) * 3;
+    T.resize((size_t)nb * m); Df.resize((size_t)nb * 18); x.resize(nb * n); path.resize(nb * np);
+    lb.resize(nb * n); ub.resize(nb * n); cost.resize(nb); nev.resize(nb); code.resize(nb);
+    for (int k = 0; k < nb; ++k) {
+      const int b = order[lo + k];
+      std::copy_n(&T_[T_at_[b]], m, &T[(size_t)k * m]);
+      std::copy_n(&Df_[(size_t)b * 18], 18, &Df[(size_t)k * 18]);
+      std::copy_n(&x_[x_at_[b]], n, &x[k * n]);
+      std::copy_n(&path_[path_at_[b]], np, &path[k * np]);
+    }
+    gtop_default_bounds(nb, m, path.data(), cfg_.bos, cfg_.vos, cfg_.aos, lb.data(), ub.data());   // :151-179
+    if ((last_status_ = gtop_group_set_problem(grp_, nb, m, T.data(), m, Df.data())) != GTOP_OK) return true;
+    last_status_ = gtop_group_optimize_batch_ex(grp_, nb, x.data(), lb.data(), ub.data(), &stop, cost.data(), nev.data(),
+                                                code.data());
+    if (last_status_ != GTOP_OK) return true;
+    for (int k = 0; k < nb; ++k) {
+      const int b = order[lo + k];
+      std::copy_n(&x[k * n], n, &x_[x_at_[b]]);
+      min_cost_[b] = cost[k];
+      nevals_[b] = nev[k];
+    }
+    lo = hi;
+  }
   return true;
 }
 
 void GradTrajBatch::getCoefficient(int b, Matrix &coeff) const {
-  coeff.resize(m_, 18);
-  if (b < 0 || b >= B_) return;
-  const int num_dp = 3 * m_ - 3;
-  const double *df = &Df_[(size_t)b * 18], *x = &x_[(size_t)b * 3 * num_dp];
+  if (b < 0 || b >= B_) {
+    coeff.resize(0, 18);
+    return;
+  }
+  const int m = m_of_[b], num_dp = 3 * m - 3;
+  coeff.resize(m, 18);
+  const double *df = &Df_[(size_t)b * 18], *x = &x_[x_at_[b]], *T = &T_[T_at_[b]];
   for (int a = 0; a < 3; ++a) {
     auto wp = [&](int j, int der) -> double {
       if (j == 0) return df[a * 6 + der];
-      if (j == m_) return df[a * 6 + 3 + der];
+      if (j == m) return df[a * 6 + 3 + der];
       return x[(size_t)a * num_dp + 3 * (j - 1) + der];
     };
-    for (int s = 0; s < m_; ++s) {
+    for (int s = 0; s < m; ++s) {
       const double d[6] = {wp(s, 0), wp(s + 1, 0), wp(s, 1), wp(s + 1, 1), wp(s, 2), wp(s + 1, 2)};
       double c[6];
-      quintic_from_boundary(d, T_[(size_t)b * m_ + s], c);
+      quintic_from_boundary(d, T[s], c);
       for (int j = 0; j < 6; ++j) coeff(s, 6 * a + j) = c[j];
     }
   }

@@ -133,12 +133,14 @@ class GradTrajBatch {
 
   void initSDFMap(Vec3 map_size_3d, Vec3 origin, double resolution);
   void updateSDFMap(const std::vector<Vec3> &obs);
-  // B waypoint lists of the same length (m + 1 >= 3 points each): segment times, Df and the straight-line start as
-  // GradTrajOptimizer::setPath makes them (src/grad_traj_optimizer.cpp:67-110)
+  // B waypoint lists of m_b + 1 >= 3 points each — the lengths may differ (candidate paths of a planner seldom have the
+  // same number of waypoints): segment times, Df and the straight-line start as GradTrajOptimizer::setPath makes
+  // them (src/grad_traj_optimizer.cpp:67-110); trajectories of equal segment count form one device problem
   void setPaths(const std::vector<std::vector<Vec3>> &way_points);
   // every trajectory's LD_MMA run (:128-243), all at once; stop rules: cfg.max_evals and the step's time limit
   bool optimizeTrajectories(int step);
-  void getCoefficient(int b, Matrix &coeff) const;               // trajectory b, m x 18
+  void getCoefficient(int b, Matrix &coeff) const;               // trajectory b, m_b x 18
+  int segments(int b) const { return (b >= 0 && b < B_) ? m_of_[b] : 0; }
   const std::vector<double> &costs() const { return min_cost_; }  // the minimum each trajectory reached
   const std::vector<int> &evaluations() const { return nevals_; }
   int size() const { return B_; }
@@ -151,7 +153,10 @@ class GradTrajBatch {
   GradTrajOptimizer::Config cfg_;
   gtop_group *grp_ = nullptr;
   int last_status_ = GTOP_OK;
-  int B_ = 0, m_ = 0;
+  int B_ = 0;
+  // per trajectory: segment count and where its rows start in the flat arrays (waypoints x 3, times, free variables)
+  std::vector<int> m_of_;
+  std::vector<size_t> path_at_, T_at_, x_at_;
   std::vector<double> path_, T_, Df_, x_, min_cost_;
   std::vector<int> nevals_;
 };

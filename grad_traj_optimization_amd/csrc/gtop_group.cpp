@@ -74,6 +74,9 @@ struct Member {
   double *cost_all = nullptr, *grad_all = nullptr;                                      // gathered: n * per rows
   double *lb = nullptr, *ub = nullptr;
   int32_t *nev = nullptr, *code = nullptr;
+  // capacities (bytes) of the buffers above, in free_slices' order: a new problem reuses what is large enough, so a
+  // caller that walks through problems of different sizes (GradTrajBatch: one per segment count) does not reallocate
+  size_t cap[11] = {0};
   ncclComm_t comm = nullptr;
 };
 
@@ -113,6 +116,18 @@ void free_slices(Member &mb) {
     if (p) (void)hipFree(p);
   mb.x = mb.Df = mb.T = mb.cost = mb.grad = mb.cost_all = mb.grad_all = mb.lb = mb.ub = nullptr;
   mb.nev = mb.code = nullptr;
+  for (size_t &c : mb.cap) c = 0;
+}
+
+// grow-only device buffer (the member's device is current)
+template <typename P> hipError_t ensure(P *&p, size_t &cap, size_t bytes) {
+  if (bytes <= cap && p) return hipSuccess;
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+  const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), bytes ? bytes : 8);
+  if (e == hipSuccess) cap = bytes ? bytes : 8;
+  return e;
 }
 
 // results of every slice to every member.  RCCL: one all-gather per member inside a group call (the slices are
@@ -316,18 +331,18 @@ int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_ti
   g->x_resident = false;
   for (int i = 0; i < n; ++i) {
     Member &mb = g->mem[i];
-    free_slices(mb);
     mb.first = std::min(B, i * per);
     mb.count = std::min(B, mb.first + per) - mb.first;
     GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipStreamSynchronize(mb.stream));   // (nothing of the previous problem may still be running on these buffers)
     // slices padded to `per` rows (RCCL's all-gather sends equal counts); the padding is never read as a result
-    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.x), (size_t)per * nvar * sizeof(double)));
-    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.Df), (size_t)per * 18 * sizeof(double)));
-    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.T), (time_stride ? (size_t)per * m : (size_t)m) * sizeof(double)));
-    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.cost), (size_t)per * sizeof(double)));
-    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.grad), (size_t)per * nvar * sizeof(double)));
-    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.cost_all), (size_t)n * per * sizeof(double)));
-    GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.grad_all), (size_t)n * per * nvar * sizeof(double)));
+    GHIP(g, ensure(mb.x, mb.cap[0], (size_t)per * nvar * sizeof(double)));
+    GHIP(g, ensure(mb.Df, mb.cap[1], (size_t)per * 18 * sizeof(double)));
+    GHIP(g, ensure(mb.T, mb.cap[2], (time_stride ? (size_t)per * m : (size_t)m) * sizeof(double)));
+    GHIP(g, ensure(mb.cost, mb.cap[3], (size_t)per * sizeof(double)));
+    GHIP(g, ensure(mb.grad, mb.cap[4], (size_t)per * nvar * sizeof(double)));
+    GHIP(g, ensure(mb.cost_all, mb.cap[5], (size_t)n * per * sizeof(double)));
+    GHIP(g, ensure(mb.grad_all, mb.cap[6], (size_t)n * per * nvar * sizeof(double)));
     GHIP(g, hipMemsetAsync(mb.cost, 0, (size_t)per * sizeof(double), mb.stream));
     GHIP(g, hipMemsetAsync(mb.grad, 0, (size_t)per * nvar * sizeof(double), mb.stream));
     if (mb.count > 0) {
@@ -451,12 +466,10 @@ int gtop_group_optimize_batch_ex(gtop_group *g, int B, double *x, const double *
     if (mb.count == 0) continue;
     GHIP(g, hipSetDevice(mb.device));
     const size_t bytes = (size_t)mb.count * nvar * sizeof(double);
-    if (!mb.lb) {
-      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.lb), (size_t)g->per * nvar * sizeof(double)));
-      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.ub), (size_t)g->per * nvar * sizeof(double)));
-      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.nev), (size_t)g->per * sizeof(int32_t)));
-      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.code), (size_t)g->per * sizeof(int32_t)));
-    }
+    GHIP(g, ensure(mb.lb, mb.cap[7], (size_t)g->per * nvar * sizeof(double)));
+    GHIP(g, ensure(mb.ub, mb.cap[8], (size_t)g->per * nvar * sizeof(double)));
+    GHIP(g, ensure(mb.nev, mb.cap[9], (size_t)g->per * sizeof(int32_t)));
+    GHIP(g, ensure(mb.code, mb.cap[10], (size_t)g->per * sizeof(int32_t)));
     GHIP(g, hipMemcpyAsync(mb.x, x + (size_t)mb.first * nvar, bytes, hipMemcpyHostToDevice, mb.stream));
     GHIP(g, hipMemcpyAsync(mb.lb, lb + (size_t)mb.first * nvar, bytes, hipMemcpyHostToDevice, mb.stream));
     GHIP(g, hipMemcpyAsync(mb.ub, ub + (size_t)mb.first * nvar, bytes, hipMemcpyHostToDevice, mb.stream));

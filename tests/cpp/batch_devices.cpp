@@ -4,7 +4,8 @@
 // GradTrajOptimizer per trajectory (optimize_on_device: the single-problem form of the same loop).  Prints one JSON
 // object that tests/test_gpu_group.py checks.
 //
-//   gtop_batch_devices <scene.txt> <B> <max_evals> <device> [<device> ...]
+//   gtop_batch_devices <scene.txt> <B> <max_evals> <device> [<device> ...] [ragged]
+// ragged: every third copy loses one interior waypoint, every third two — three segment counts in one batch.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,7 +48,11 @@ int main(int argc, char **argv) {
   }
   const int B = std::atoi(argv[2]);
   std::vector<int> devices;
-  for (int i = 4; i < argc; ++i) devices.push_back(std::atoi(argv[i]));
+  bool ragged = false;
+  for (int i = 4; i < argc; ++i) {
+    if (std::string(argv[i]) == "ragged") ragged = true;
+    else devices.push_back(std::atoi(argv[i]));
+  }
   GradTrajOptimizer::Config cfg;
   cfg.max_evals = std::atoi(argv[3]);
   cfg.time_limit_2 = 30.0;   // evaluation-capped: reproducible
@@ -55,6 +60,11 @@ int main(int argc, char **argv) {
   for (int b = 0; b < B; ++b)
     for (size_t i = 1; i + 1 < waypoints.size(); ++i) lists[b][i][0] += 0.01 * (b % 17) - 0.05 * ((b / 17) % 3);
 
+  if (ragged && waypoints.size() >= 8)
+    for (int b = 0; b < B; ++b) {
+      if (b % 3 >= 1) lists[b].erase(lists[b].begin() + 5);
+      if (b % 3 == 2) lists[b].erase(lists[b].begin() + 2);
+    }
   GradTrajBatch batch(devices, cfg);
   if (!batch.ok()) { std::fprintf(stderr, "GradTrajBatch: %s\n", batch.lastError()); return 2; }
   batch.initSDFMap(map_size, origin, resolution);
@@ -81,12 +91,16 @@ int main(int argc, char **argv) {
     Matrix ca, cb;
     one.getCoefficient(ca);
     batch.getCoefficient(b, cb);
+    if (ca.a.size() != cb.a.size() || batch.segments(b) != (int)lists[b].size() - 1) return 4;
     for (size_t i = 0; i < ca.a.size(); ++i) max_coeff = std::fmax(max_coeff, std::fabs(ca.a[i] - cb.a[i]));
   }
   int min_ev = 1 << 30, max_ev = 0;
   for (int e : batch.evaluations()) { min_ev = e < min_ev ? e : min_ev; max_ev = e > max_ev ? e : max_ev; }
+  int min_m = 1 << 30, max_m = 0;
+  for (int b = 0; b < B; ++b) { const int m = batch.segments(b); min_m = m < min_m ? m : min_m; max_m = m > max_m ? m : max_m; }
   std::printf("{\"B\": %d, \"devices\": %d, \"gather\": \"%s\", \"max_rel_cost_diff\": %.3g, \"max_coeff_diff\": %.3g, "
-              "\"min_evals\": %d, \"max_evals\": %d, \"cost0\": %.17g}\n",
-              batch.size(), batch.devices(), batch.gatherBackend(), max_rel, max_coeff, min_ev, max_ev, batch.costs()[0]);
+              "\"min_evals\": %d, \"max_evals\": %d, \"min_segments\": %d, \"max_segments\": %d, \"cost0\": %.17g}\n",
+              batch.size(), batch.devices(), batch.gatherBackend(), max_rel, max_coeff, min_ev, max_ev, min_m, max_m,
+              batch.costs()[0]);
   return 0;
 }

@@ -119,3 +119,26 @@ def test_cpp_batch_class_over_the_group(tmp_path):
     assert r["B"] == 200 and r["devices"] == 3 and r["gather"] == "copy"
     assert r["min_evals"] == r["max_evals"] == 30
     assert r["max_rel_cost_diff"] <= 1e-9 and r["max_coeff_diff"] <= 1e-9, r
+
+
+def test_cpp_batch_class_with_differing_waypoint_counts(tmp_path):
+    """A ragged batch: the copies of the opti_node path with 11, 10 and 9 waypoints in turn (candidate paths seldom
+    agree on their number of waypoints).  GradTrajBatch forms one device problem per segment count over the same
+    group (slice buffers reused, the field untouched) and hands every trajectory its own result: the same minimum
+    and coefficients as one GradTrajOptimizer object per path."""
+    import json
+    import os
+    import subprocess
+    from tests import scenes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "grad_traj_optimization_amd", "gtop_batch_devices")
+    assert os.path.exists(exe), "build() did not produce gtop_batch_devices"
+    f = scenes.write_scene(tmp_path / "opti_node.txt", scenes.OPTI_NODE_MAP_SIZE, scenes.OPTI_NODE_ORIGIN,
+                           scenes.OPTI_NODE_RES, scenes.opti_node_obstacles(), scenes.OPTI_NODE_PATH)
+    out = subprocess.run([exe, str(f), "100", "25", "0", "0", "ragged"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    r = json.loads(out.stdout[out.stdout.index("{"):])
+    assert r["B"] == 100 and r["devices"] == 2
+    assert (r["min_segments"], r["max_segments"]) == (8, 10)
+    assert r["min_evals"] == r["max_evals"] == 25
+    assert r["max_rel_cost_diff"] <= 1e-9 and r["max_coeff_diff"] <= 1e-9, r
