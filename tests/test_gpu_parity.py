@@ -86,6 +86,28 @@ def test_esdf_grid_shapes_bit_exact(gtop, grid, kind):
     assert np.array_equal(d, ref)
 
 
+def test_esdf_every_distance_the_packed_sweep_can_produce(gtop):
+    """One obstacle in the corner of a 256^3 map: the squared distances are ALL sums of three squares of 0 .. 255 —
+    every value below 2^16 the packed x sweep's own square root (esdf_sqrt_u16: the hardware estimate + Goldschmidt,
+    without the library routine's rescaling) can ever be handed, and the saturated ones beyond for the 32-bit path.
+    Bit for bit res * sqrt(n) with numpy's exactly rounded sqrt."""
+    n = 256
+    res = 0.2
+    occ = np.zeros((n, n, n), dtype=np.uint8)
+    occ[0, 0, 0] = 1
+    mp = problem.MapSpec((n, n, n), res, np.array([-n * res / 2, -n * res / 2, 0.0]), occ)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, res)
+    assert tuple(ctx.grid) == (n, n, n)
+    ctx.update_sdf_map(mp.obstacle_points())
+    d = ctx.get_sdf().reshape(n, n, n)
+    i = np.arange(n, dtype=np.float64)
+    sq = i[:, None, None] ** 2 + i[None, :, None] ** 2 + i[None, None, :] ** 2
+    assert len(np.unique(sq[sq < 65535])) > 50000          # (most integers are sums of three squares)
+    assert np.array_equal(d, res * np.sqrt(sq))
+    ctx.close()
+
+
 @pytest.mark.parametrize("m", [2, 3, 6, 7, 10, 12, 17])
 @pytest.mark.parametrize("kw", [dict(), dict(step=1), dict(wc=0.0), dict(ws=0.0), dict(ws=20.0, wc=1.0)])
 def test_fp64_parity_host_api(scene, oracle_mod, m, kw):
