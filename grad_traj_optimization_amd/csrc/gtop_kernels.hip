@@ -573,8 +573,7 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
 //     (end of segment w-1 + start of segment w) straight from the tile, adds
 //     1e-5 and stores; the scalar cost is a DPP wavefront sum of the lanes'
 //     cost accumulators, no LDS at all.
-// Same arithmetic as gtop_eval_kernel sample for sample; only the order of the
-// final sums differs (measured against the oracle: <= 1e-12).
+// Against the oracle: <= 1e-12 (only the order of the final sums differs from the reference's loop).
 // Host-checked: NT*m <= 64/LPS, one workgroup per group of NT trajectories.
 // ---------------------------------------------------------------------------
 // COLLI = false is the |wc| < 1e-4 case (:346, no collision term), decided by the launcher: the kernel body is
@@ -662,7 +661,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   constexpr int kTileRows = LONG ? 18 : kRedVals;          // (LONG sums the cost in registers)
   GTOP_STAMP(1);
 
-  // XCD-aware order (see gtop_eval_kernel): XCD x gets the x-th contiguous eighth of the batch
+  // XCD-aware order (workgroup id mod 8 = XCD): XCD x gets the x-th contiguous eighth of the batch
   const int ngroups = (a.B + NT - 1) / NT;
   const int per_xcd = (ngroups + 7) >> 3;
   // The grid is 8*per_xcd workgroups; the up to 7 beyond the batch take no early exit (a branch here would
@@ -883,13 +882,11 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
 
   // ---- collision samples (:345-409); sample index = li + j*LPS ----
   if constexpr (COLLI) {
-    // Sample times (:353, see gtop_eval_kernel): t_i = 1e-3 + i*dt; segments with T < 0.0301 (where the
+    // Sample times (:353): t_i = 1e-3 + i*dt; segments with T < 0.0301 (where the
     // sample COUNT depends on the accumulated value) replay the reference's addition chain.
     // Every term of a sample carries the factor alpha * wc * dt (cd of :509 times the weights of :373/:417);
     // a sample past the loop bound of :353 contributes nothing, i.e. has that factor zero.  With T >= 0.0301
     // all 30 samples are inside the bound, so only the replay path ever has to clear it.
-    // Sample times (:353, see gtop_eval_kernel): t_i = 1e-3 + i*dt; segments with T < 0.0301 (where the
-    // sample COUNT depends on the accumulated value) replay the reference's addition chain.
     const bool tiny_T = T < (R)0.0301;
     const bool any_tiny = __ballot(tiny_T) != 0ull;   // wave-uniform, rare
     // The quotient proper (:351) is only needed on that replay path; the empty asm keeps the dozen instructions of

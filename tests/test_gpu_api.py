@@ -427,7 +427,7 @@ def test_full_size_batch_properties(full_scene, oracle_mod, cfg):
     # halves vs whole, with the launch geometry pinned (the auto rule picks the body by batch size, and
     # another body is another summation order): samples per lane 3 = one wavefront per trajectory
     # whatever B, 6 = the one-trajectory body for the halves and the two-trajectory body for the whole
-    # when B is even -> both must still agree bit for bit within one pinned geometry at equal tpb
+    # when B is even -> both must still agree bit for bit within one pinned geometry
     h = B // 2
     try:
         ctx.set_launch_geometry(1, 3)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 --pmc CSVs written by tools/pmc_collect.sh: per-launch
-averages for the evaluation kernel (gtop_eval_kernel / gtop_eval_wave_kernel), plus the HBM-traffic figure used by bench.py's
+averages for the evaluation kernel (gtop_eval_wave_kernel), plus the HBM-traffic figure used by bench.py's
 roofline.traffic.
 
 Traffic rule (MI355X_MICROARCH.md §HBM): FETCH_SIZE/WRITE_SIZE are in KiB;
