@@ -653,3 +653,57 @@ def test_batch_past_the_grid_limit(full_scene):
         assert torch.equal(cv[k], cv[0]) and torch.equal(gv[k], gv[0])
     assert torch.max(torch.abs(cv[0] - c1) / c1).item() <= 1e-12
     assert torch.max(torch.abs(gv[0] - g1)).item() <= 1e-9 * torch.max(torch.abs(g1)).item()
+
+
+def test_contexts_in_concurrent_host_threads(gtop, oracle_mod):
+    """include/gtop.h: one gtop_ctx per host thread.  Four threads, each with its own context, map and batch on device
+    0, evaluating and optimising at the same time (ctypes drops the GIL for the calls): every thread's results are
+    bit for bit what the same calls give one after the other — nothing is shared between contexts."""
+    import threading
+    jobs = []
+    for k in range(4):
+        mp = problem.make_map((40 + 4 * k, 36, 20 + k), density=0.03, seed=70 + k)
+        b = problem.make_trajectories(200 + 37 * k, 4 + 2 * k, mp, seed=80 + k, step_len=(0.5, 1.2))
+        jobs.append((mp, b))
+
+    def work(mp, b, out):
+        ctx = gtop.GtopContext(device=0)
+        ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+        ctx.update_sdf_map(mp.obstacle_points())
+        ctx.set_problem(b.T, b.Df)
+        res = []
+        for it in range(20):
+            res.append(ctx.eval_batch(b.x + 0.001 * it))
+        lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+        res.append(ctx.optimize_batch(b.x, lb, ub, 8))
+        ctx.close()
+        out.append(res)
+
+    serial = []
+    for mp, b in jobs:
+        out = []
+        work(mp, b, out)
+        serial.append(out[0])
+    outs = [[] for _ in jobs]
+    errs = []
+
+    def guarded(mp, b, out):
+        try:
+            work(mp, b, out)
+        except Exception as e:          # (a failure must reach the test, not die with the thread)
+            errs.append(e)
+
+    threads = [threading.Thread(target=guarded, args=(mp, b, o), daemon=True) for (mp, b), o in zip(jobs, outs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert all(not t.is_alive() for t in threads)
+    for k in range(4):
+        for (a0, a1), (s0, s1) in zip(outs[k][0], serial[k]):
+            assert np.array_equal(a0, s0) and np.array_equal(a1, s1), k
+    sdf = oracle_mod.Sdf.from_map_size(jobs[3][0].origin, jobs[3][0].resolution, jobs[3][0].map_size)
+    sdf.build_from_occupancy(jobs[3][0].occupancy)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(jobs[3][1].T, jobs[3][1].Df, jobs[3][1].x, sdf, oracle_mod.make_params(), nthreads=8)
+    assert np.max(np.abs(serial[3][0][0] - c_ref) / np.abs(c_ref)) <= 1e-5
