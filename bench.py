@@ -625,27 +625,31 @@ def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
         lb, ub = gtop.GtopContext.default_bounds(batch.waypoints[:x.shape[0]])
         lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
         evals = 50
-        xo = x.clone()
-        ctx.optimize_device(xo, Df, T, lbt, ubt, evals)       # warm-up
-        torch.cuda.synchronize()
-        xo = x.clone()
-        t0 = time.perf_counter()
-        _, cmin = ctx.optimize_device(xo, Df, T, lbt, ubt, evals)
-        torch.cuda.synchronize()
-        dt_s = time.perf_counter() - t0
+        def run_optimizer():
+            """Host clock around one whole optimisation of the batch (launches + completion), the median of five runs
+            after 40 ms of the same runs: after the seconds of host work before it the card needs 10-20 ms of load
+            to reach its sustained clocks (tools/clock_ramp.py), and a single cold run read 5-30 % long."""
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.040:
+                ctx.optimize_device(x.clone(), Df, T, lbt, ubt, evals)
+                torch.cuda.synchronize()
+            secs, res = [], None
+            for _ in range(5):
+                xo = x.clone()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = ctx.optimize_device(xo, Df, T, lbt, ubt, evals)
+                torch.cuda.synchronize()
+                secs.append(time.perf_counter() - t0)
+            return sorted(secs)[2], res[1]
+
+        dt_s, cmin = run_optimizer()
         c0, _ = ctx.eval_device(x, Df, T)
         torch.cuda.synchronize()
         other = {}
         for mode, key in ((1, "seconds_one_launch_per_iteration"), (0, "seconds_with_separate_update_launch")):
             ctx.set_optimizer_fusion(mode)
-            xo2 = x.clone()
-            ctx.optimize_device(xo2, Df, T, lbt, ubt, evals)
-            torch.cuda.synchronize()
-            xo2 = x.clone()
-            t0 = time.perf_counter()
-            ctx.optimize_device(xo2, Df, T, lbt, ubt, evals)
-            torch.cuda.synchronize()
-            other[key] = time.perf_counter() - t0
+            other[key], _ = run_optimizer()
         ctx.set_optimizer_fusion(2)
         out["optimizer"] = {
             "what": "batched CCSA-MMA on the device, whole loop in one launch (replaces per-problem NLopt LD_MMA)",
