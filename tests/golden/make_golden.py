@@ -102,6 +102,13 @@ def case_small_maps():
         add(f"m{m}_kino", bk.T, bk.Df, bk.x, base)
     bk = problem.make_trajectories(4, 6, mp, seed=93, step_len=(0.5, 1.0), margin=0.4, boundary="random")
     add("m6_kino_dyn", bk.T, bk.Df, bk.x, dict(base, enable_dyn=1, alpha_v=2.0, alpha_a=1.5))
+    # round 3's bodies: 9 segments (two wavefronts per trajectory for a batch this small), 17 and 30 (the chunked body past
+    # 12 segments: two and three chunks), the latter with the dyn block as well
+    for m in (9, 17, 30):
+        bk = problem.make_trajectories(3, m, mp, seed=100 + m, step_len=(0.4, 0.8), margin=0.4, boundary="random")
+        add(f"m{m}_kino", bk.T, bk.Df, bk.x, base)
+    bk = problem.make_trajectories(3, 17, mp, seed=131, step_len=(0.4, 0.8), margin=0.4, boundary="random")
+    add("m17_kino_dyn", bk.T, bk.Df, bk.x, dict(base, enable_dyn=1, alpha_v=2.0, r_v=4.0, alpha_a=1.5, r_a=15.0))
     # samples leaving the map: waypoints pushed through the boundary (dist = -1, grad = 0 convention)
     b2 = problem.make_trajectories(4, 4, mp, seed=78, step_len=(0.5, 1.0), margin=0.4)
     x2 = b2.x.copy()
