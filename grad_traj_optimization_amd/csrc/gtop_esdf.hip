@@ -167,12 +167,14 @@ esdf_z_small_kernel(const GtopGrid g, const uint8_t *__restrict__ occ, int *__re
     }
     if (lane == 0) colany[col] = any != 0ull;   // the column holds an obstacle: finite for the y sweep
     if (any == 0ull) {   // (wave-uniform) most columns of a map are empty: nothing to search
+      // ... and, for the packed y sweep (out16 set), nothing to store: esdf_y16_kernel reads only columns that hold an
+      // obstacle (its candidates; a voxel's own column by the same flag), so an empty column's 6 bytes per voxel —
+      // most of this sweep's stores — are never looked at
+      if (!out16) {
 #pragma unroll
-      for (int ko = 0; ko < NCH; ++ko) {
-        const int z = ko * 64 + lane;
-        if (z < nz) {
-          out[col * nz + z] = kInf;
-          if (out16) out16[col * nz + z] = 0xFFFF;
+        for (int ko = 0; ko < NCH; ++ko) {
+          const int z = ko * 64 + lane;
+          if (z < nz) out[col * nz + z] = kInf;
         }
       }
       continue;
@@ -520,7 +522,11 @@ esdf_y16_kernel(const GtopGrid g, const uint16_t *__restrict__ fin16, const int 
     s2.y = (unsigned short)d2;
     return s2;
   };
-  PkV best = *reinterpret_cast<const PkV *>(fin16 + i);
+  // the voxels' own column: read only if it holds an obstacle (the z sweep stores nothing for the others)
+  const bool own = k0 < c && cx(k0) == q;
+  PkV best;
+  best.p[0] = best.p[1] = best.p[2] = best.p[3] = splat(0xFFFF);
+  if (own) best = *reinterpret_cast<const PkV *>(fin16 + i);
   auto worst_of = [&]() {
     const gtop_u16x2 w = __builtin_elementwise_max(__builtin_elementwise_max(best.p[0], best.p[1]),
                                                    __builtin_elementwise_max(best.p[2], best.p[3]));
@@ -571,7 +577,9 @@ esdf_y16_kernel(const GtopGrid g, const uint16_t *__restrict__ fin16, const int 
     for (int h = 0; h < 2; ++h) {
       const int ih = i + 4 * h;
       const int *line = fin + lbase + 4 * h;
-      IntV<4> b32 = load_v<4>(fin + ih);
+      IntV<4> b32;
+      b32.v[0] = b32.v[1] = b32.v[2] = b32.v[3] = kInf;
+      if (own) b32 = load_v<4>(fin + ih);
       int w32 = max(max(b32.v[0], b32.v[1]), max(b32.v[2], b32.v[3]));
       for (int k = k0 - 1; k >= 0; --k) {
         const int vv = cx(k), d = q - vv, d2 = __mul24(d, d);
