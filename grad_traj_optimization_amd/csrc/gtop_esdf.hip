@@ -611,14 +611,9 @@ esdf_y16_kernel(const GtopGrid g, const uint16_t *__restrict__ fin16, const int 
     }
     return;
   }
-  if (has_work) {   // every value is below 0xFFFF: the 16-bit words ARE the exact minima
-    IntV<4> lo4, hi4;
-    lo4.v[0] = best.p[0].x; lo4.v[1] = best.p[0].y; lo4.v[2] = best.p[1].x; lo4.v[3] = best.p[1].y;
-    hi4.v[0] = best.p[2].x; hi4.v[1] = best.p[2].y; hi4.v[2] = best.p[3].x; hi4.v[3] = best.p[3].y;
-    *reinterpret_cast<IntV<4> *>(fout + i) = lo4;
-    *reinterpret_cast<IntV<4> *>(fout + i + 4) = hi4;
-    if (fout16) *reinterpret_cast<PkV *>(fout16 + i) = best;
-  }
+  // every value is below 0xFFFF: the 16-bit words ARE the exact minima, and the only copy stored — the x sweep reads
+  // the int32 output only where the 16-bit one says 0xFFFF (esdf_x_scan_block), i.e. in the wavefronts above
+  if (has_work) *reinterpret_cast<PkV *>(fout16 + i) = best;
 }
 
 // x sweep (sdf_map.cpp:348-364): out(q) = min_v ((q-v)^2 + in(v)), scanning outward; then
@@ -703,8 +698,24 @@ __device__ __forceinline__ int esdf_empty_run(const EsdfSlabRuns *sr, int n, int
 template <int V>
 __device__ __forceinline__ void esdf_x_scan_block(const GtopGrid &g, const int *__restrict__ fin, double *__restrict__ dist,
                                                   float *__restrict__ dist32, const int first, const int q0,
-                                                  const EsdfSlabRuns *sr) {
+                                                  const EsdfSlabRuns *sr, const uint16_t *__restrict__ f16 = nullptr) {
   constexpr int kScanBatch = 4;   // steps per round trip
+  // f16 set (the packed x sweep's exact fallback, V = 4): the packed y sweep stores its int32 output only where the
+  // 16-bit copy is saturated (whole wavefronts of it), so a row is read from the 16-bit copy — exact wherever it is
+  // below 0xFFFF — and from the int32 output only where it is not
+  auto load_row = [&](int idx) -> IntV<V> {
+    if constexpr (V == 4) {
+      if (f16) {
+        const uint2 pk = *reinterpret_cast<const uint2 *>(f16 + idx);
+        IntV<4> r;
+        r.v[0] = (int)(pk.x & 0xFFFFu); r.v[1] = (int)(pk.x >> 16);
+        r.v[2] = (int)(pk.y & 0xFFFFu); r.v[3] = (int)(pk.y >> 16);
+        if (max(max(r.v[0], r.v[1]), max(r.v[2], r.v[3])) == 0xFFFF) r = load_v<4>(fin + idx);
+        return r;
+      }
+    }
+    return load_v<V>(fin + idx);
+  };
   const int nyz = g.ny * g.nz;
   const int n = g.nx;
   const int last = first + (n - 1) * nyz;   // the line's end voxels: first, last
@@ -714,7 +725,7 @@ __device__ __forceinline__ void esdf_x_scan_block(const GtopGrid &g, const int *
 #pragma unroll
   for (int e = 0; e < kXB; ++e) {
     row[e] = first + min(q0 + e, n - 1) * nyz;
-    best[e] = load_v<V>(fin + row[e]);
+    best[e] = load_row(row[e]);
   }
   {
     IntV<V> own[kXB];
@@ -765,8 +776,8 @@ __device__ __forceinline__ void esdf_x_scan_block(const GtopGrid &g, const int *
     for (int u = 0; u < kScanBatch; ++u) {
       lo = max(lo - nyz, first);
       hi = min(hi + nyz, last);
-      flo[u] = load_v<V>(fin + lo);
-      fhi[u] = load_v<V>(fin + hi);
+      flo[u] = load_row(lo);
+      fhi[u] = load_row(hi);
     }
 #pragma unroll
     for (int u = 0; u < kScanBatch; ++u) {
@@ -995,8 +1006,8 @@ esdf_x16_kernel(const GtopGrid g, const uint16_t *__restrict__ f16, const int *_
     worst = worst_of();
   }
   if (__any(worst == 0xFFFF)) {   // (wave-uniform) a minimum at or past 2^16 - 1: the exact 32-bit scan instead
-    esdf_x_scan_block<4>(g, fin, dist, dist32, first, q0, sr);
-    esdf_x_scan_block<4>(g, fin, dist, dist32, first + 4, q0, sr);
+    esdf_x_scan_block<4>(g, fin, dist, dist32, first, q0, sr, f16);
+    esdf_x_scan_block<4>(g, fin, dist, dist32, first + 4, q0, sr, f16);
     return;
   }
 #ifdef GTOP_ESDF_STAMPS
