@@ -142,3 +142,33 @@ def test_cpp_batch_class_with_differing_waypoint_counts(tmp_path):
     assert (r["min_segments"], r["max_segments"]) == (8, 10)
     assert r["min_evals"] == r["max_evals"] == 25
     assert r["max_rel_cost_diff"] <= 1e-9 and r["max_coeff_diff"] <= 1e-9, r
+
+
+def test_group_walks_through_problems_of_different_sizes(scene, gtop):
+    """One group, problem after problem (as GradTrajBatch does per segment count): the slice buffers are reused where
+    large enough and grown where not, the replicated maps are rebuilt in between — every result the unsharded one's."""
+    mp, ctx = scene
+    g = _group(gtop, mp, [0, 0, 0])
+    ctx.set_params()
+    rng = np.random.default_rng(5)
+    for k, (B, m) in enumerate([(500, 6), (40, 12), (900, 3), (7, 17), (901, 6), (2, 2)]):
+        if k == 3:      # another map half way: every member rebuilds its copy, the single context too
+            mp2 = problem.make_map((60, 50, 30), density=0.05, seed=99)
+            g.update_sdf_map(mp2.obstacle_points())
+            ctx.update_sdf_map(mp2.obstacle_points())
+        b = problem.make_trajectories(B, m, mp, seed=200 + k, step_len=(0.4, 0.9), boundary="random" if k % 2 else None)
+        ctx.set_problem(b.T, b.Df)
+        g.set_problem(b.T, b.Df)
+        c_ref, g_ref = ctx.eval_batch(b.x)
+        c, gr = g.eval_batch(b.x)
+        assert np.array_equal(c, c_ref) and np.array_equal(gr, g_ref), (k, B, m)
+        for ci, gi in g.eval_resident(gather=2):
+            assert np.array_equal(ci, c_ref) and np.array_equal(gi, g_ref), (k, B, m)
+        if k in (1, 4):
+            lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+            ref = ctx.optimize_batch_ex(b.x, lb, ub, int(rng.integers(5, 15)))
+            got = g.optimize_batch_ex(b.x, lb, ub, ref[2].max())
+            for a, r in zip(got, ref):
+                assert np.array_equal(a, r), (k, B, m)
+    ctx.update_sdf_map(mp.obstacle_points())     # (the module's scene as the other tests expect it)
+    g.close()
