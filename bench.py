@@ -651,6 +651,10 @@ def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
             ctx.set_optimizer_fusion(mode)
             other[key], _ = run_optimizer()
         ctx.set_optimizer_fusion(2)
+        ctx.set_optimizer_precision("f32")      # the same loop with its evaluations in fp32 (state, update, results fp64)
+        other["seconds_with_fp32_evaluations"], cmin32 = run_optimizer()
+        ctx.set_optimizer_precision("f64")
+        other["median_cost_ratio_fp32_evaluations_vs_fp64"] = float(torch.median(cmin32 / cmin).item())
         out["optimizer"] = {
             "what": "batched CCSA-MMA on the device, whole loop in one launch (replaces per-problem NLopt LD_MMA)",
             "batch": int(x.shape[0]), "evals_per_trajectory": evals, "seconds": dt_s,

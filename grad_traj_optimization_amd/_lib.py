@@ -131,6 +131,7 @@ def load_library():
         "gtop_rendezvous_abort": (C.c_int, [vp]),
         "gtop_rendezvous_stats": (C.c_int, [vp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64)]),
         "gtop_set_optimizer_fusion": (C.c_int, [vp, C.c_int]),
+        "gtop_set_optimizer_precision": (C.c_int, [vp, C.c_int]),
         "gtop_group_create": (C.c_int, [C.POINTER(vp), ip, C.c_int]),
         "gtop_group_destroy": (C.c_int, [vp]),
         "gtop_group_size": (C.c_int, [vp]),
@@ -268,6 +269,11 @@ class GtopContext:
         evaluation kernel, one launch per iteration; 0 (or False): separate update launch."""
         mode = 2 if mode is True else int(mode)
         self._chk(self._L.gtop_set_optimizer_fusion(self._h, mode))
+
+    def set_optimizer_precision(self, dtype="f64"):
+        """"f64" (default) or "f32": the arithmetic of the evaluations inside the batched optimizer (state, update
+        and results stay fp64)."""
+        self._chk(self._L.gtop_set_optimizer_precision(self._h, {"f64": GTOP_F64, "f32": GTOP_F32}[dtype]))
 
     def set_launch_geometry(self, waves=0, samples_per_lane=0):
         self._chk(self._L.gtop_set_launch_geometry(self._h, int(waves), int(samples_per_lane)))

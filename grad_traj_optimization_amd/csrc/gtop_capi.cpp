@@ -73,6 +73,7 @@ struct gtop_ctx {
          cap_mma_ub = 0;
 
   int spl = 0;     // samples per lane: 0 = auto, 3 or 6 (gtop_set_launch_geometry)
+  int opt_dtype = GTOP_F64;   // gtop_set_optimizer_precision: the arithmetic of the evaluations inside the batched optimizer
   int fuse_mma = 2;         // optimizer: 0 separate update launch, 1 update fused into the evaluation kernel,
                             //            2 (default) the whole loop in one launch (tuning/debug knob)
 
@@ -832,6 +833,31 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   a.grad = c->mma_g;
   a.B = B; a.m = m; a.t_stride = time_stride;
   const bool dyn = c->prm.enable_dyn != 0;
+  // gtop_set_optimizer_precision(GTOP_F32): the same loop with its evaluations in fp32 on the fp32 field; the state,
+  // the bounds, Df, T, the update and every result stay fp64 (the kernel converts as it reads its inputs from LDS)
+  const bool f32 = c->opt_dtype == GTOP_F32;
+  GtopKernelArgs<float> a32;
+  if (f32) {
+    if (!fused) return fail(c, GTOP_ERR_INVALID, "optimize: fp32 evaluations need a fused launch form (gtop_set_optimizer_fusion 1 or 2)");
+    if (!c->sdf32) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
+    c->fp32_in_use = true;
+    if (c->sdf32_stale) {   // (only gtop_update_sdf_map leaves it stale, and it has synchronised: see gtop_eval_device)
+      const GtopGrid &g = c->grid;
+      HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, (size_t)g.nx * g.ny * g.nz, s));
+      c->sdf32_stale = false;
+    }
+    fill_args(c, a32);
+    a32.sdf = c->sdf32;
+    a32.x = nullptr;   // (the loop reads its trial point from LDS)
+    a32.Df = reinterpret_cast<const float *>(d_Df);   // fp64 rows: staged by the kernel as such
+    a32.T = reinterpret_cast<const float *>(d_T);
+    a32.cost = nullptr;
+    a32.grad = nullptr;
+    a32.B = B; a32.m = m; a32.t_stride = time_stride;
+  }
+  auto launch_loop = [&]() -> hipError_t {
+    return f32 ? gtop_launch_eval_mma(a32, st, plan, dyn, s) : gtop_launch_eval_mma(a, st, plan, dyn, s);
+  };
   // The whole optimisation as ONE launch: the loop initialises the state from d_x itself and writes the results where
   // they are wanted — no init kernel in front, no copies and no finish kernel behind (each a stream operation of its
   // own: 75 -> ~25 us of fixed cost per call).
@@ -843,14 +869,14 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
     st.out_minf = static_cast<double *>(d_minf);
     st.out_code = d_code;
     st.out_nevals = d_nevals;
-    HIPCHK(c, gtop_launch_eval_mma(a, st, plan, dyn, s));
+    HIPCHK(c, launch_loop());
     return GTOP_OK;
   }
   HIPCHK(c, gtop_launch_mma_init(st, B, (int)n, static_cast<const double *>(d_x), s));
   for (int it = 0; it < max_evals; ++it) {
     if (fused) {
       // one launch per iteration: the evaluation kernel runs the MMA update as its epilogue
-      HIPCHK(c, gtop_launch_eval_mma(a, st, plan, dyn, s));
+      HIPCHK(c, launch_loop());
     } else {
       if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s,
                                     /*for_optimizer=*/true)))   // the geometry the fused modes run: same bits
@@ -972,6 +998,13 @@ int gtop_set_optimizer_fusion(gtop_ctx *c, int fused) {
   if (!c) return GTOP_ERR_INVALID;
   if (fused < 0 || fused > 2) return fail(c, GTOP_ERR_INVALID, "optimizer fusion mode is 0, 1 or 2");
   c->fuse_mma = fused;
+  return GTOP_OK;
+}
+
+int gtop_set_optimizer_precision(gtop_ctx *c, int dtype) {
+  if (!c) return GTOP_ERR_INVALID;
+  if (dtype != GTOP_F64 && dtype != GTOP_F32) return fail(c, GTOP_ERR_INVALID, "optimizer precision is GTOP_F64 or GTOP_F32");
+  c->opt_dtype = dtype;
   return GTOP_OK;
 }
 

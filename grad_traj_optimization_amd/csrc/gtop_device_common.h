@@ -104,8 +104,10 @@ __device__ __forceinline__ void gtop_mma_separable_step(int n, int lane, const d
 
 // One update on the state `v` / `sc` (see gtop_mma_update_trajectory).  st: the stop tolerances only.
 // gcur: this trajectory's gradient at xcur (n values; global or LDS).
+// G: double, or float when the evaluation ran in fp32 (gtop_set_optimizer_precision): the state stays fp64.
+template <typename G>
 __device__ __forceinline__ void gtop_mma_update_core(const GtopMmaState &st, const GtopMmaVecs &v, GtopMmaScalars &sc,
-                                                     int n, int lane, double fcur, const double *gcur) {
+                                                     int n, int lane, double fcur, const G *gcur) {
   if (sc.state >= 3) return;   // stopped (wavefront-uniform): the trajectory stays as it was left
   double rho = sc.rho, minf = sc.minf;
   int k = sc.k;
@@ -117,7 +119,7 @@ __device__ __forceinline__ void gtop_mma_update_core(const GtopMmaState &st, con
     minf = fcur;
     for (int j = lane; j < n; j += 64) {
       v.x[j] = v.xcur[j];
-      v.dfdx[j] = gcur[j];
+      v.dfdx[j] = (double)gcur[j];
     }
     new_outer = true;
   } else {
@@ -127,7 +129,7 @@ __device__ __forceinline__ void gtop_mma_update_core(const GtopMmaState &st, con
       minf = fcur;
       for (int j = lane; j < n; j += 64) {
         v.x[j] = v.xcur[j];
-        v.dfdx[j] = gcur[j];
+        v.dfdx[j] = (double)gcur[j];
       }
     }
     if (inner_done) {

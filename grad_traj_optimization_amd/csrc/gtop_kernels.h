@@ -97,6 +97,8 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
 // made with for_optimizer = true); honours st.x0_init / st.out_*
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
                                 bool dyn, hipStream_t stream);
+hipError_t gtop_launch_eval_mma(const GtopKernelArgs<float> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
+                                bool dyn, hipStream_t stream);
 hipError_t gtop_launch_mma_init(const GtopMmaState &st, int B, int n, const double *x0, hipStream_t stream);
 hipError_t gtop_launch_mma_update(const GtopMmaState &st, int B, int n, const double *fcur, const double *gcur,
                                   hipStream_t stream);

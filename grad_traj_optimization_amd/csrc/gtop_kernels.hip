@@ -630,7 +630,10 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
                       const R *__restrict__ arg_sdf, int arg_B, int arg_m, int arg_t_stride, int arg_nx, int arg_ny,
                       int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K, const MM st) {
   constexpr bool MMA = !std::is_same<MM, GtopNoMma>::value;
-  static_assert(!MMA || (NT == 1 && sizeof(R) == 8), "the optimizer loop: fp64, one trajectory per wavefront");
+  static_assert(!MMA || NT == 1, "the optimizer loop: one trajectory per wavefront");
+  // the optimizer's state, bounds, Df and T are fp64 whatever R is: with R = float only the evaluation runs in fp32
+  // (its inputs converted as they are read from LDS, its cost and gradient widened for the update)
+  using In = typename std::conditional<MMA, double, R>::type;
   GtopKernelArgs<R> a = arg_rest;
   a.x = arg_x; a.Df = arg_Df; a.T = arg_T; a.sdf = arg_sdf;
   a.B = arg_B; a.m = arg_m; a.t_stride = arg_t_stride;
@@ -705,11 +708,12 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     mma_live = grp_ok;
     if (mma_live) {
       const size_t o = (size_t)b0 * n;
-      if (lane < 18) mv[8 * kMV + lane] = a.Df[(size_t)b0 * 18 + lane];
+      const double *Df64 = reinterpret_cast<const double *>(a.Df), *T64 = reinterpret_cast<const double *>(a.T);
+      if (lane < 18) mv[8 * kMV + lane] = Df64[(size_t)b0 * 18 + lane];
       if constexpr (LONG) {
-        for (int j = lane; j < m; j += 64) mv[8 * kMV + 18 + j] = a.T[(size_t)b0 * a.t_stride + j];
+        for (int j = lane; j < m; j += 64) mv[8 * kMV + 18 + j] = T64[(size_t)b0 * a.t_stride + j];
       } else {
-        if (lane < m) mv[8 * kMV + 18 + lane] = a.T[(size_t)b0 * a.t_stride + lane];
+        if (lane < m) mv[8 * kMV + 18 + lane] = T64[(size_t)b0 * a.t_stride + lane];
       }
       if (st.x0_init) {   // (uniform) a fresh problem: mma_init_kernel's arithmetic, straight into LDS
         msc = GtopMmaScalars{1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0};
@@ -765,28 +769,30 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   }
   // ---- inputs: two waypoints' (p, v, a) per axis and T_s, straight from HBM/L2 (the optimizer loop: from LDS) ----
   // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
-  const R *xb = xsrc + (size_t)b0 * n + tl * n;      // this lane's trajectory (b0: wave-uniform)
-  const R *dfb = a.Df + (size_t)b0 * 18 + tl * 18;
-  const R *Tb = a.T + (size_t)b0 * a.t_stride + tl * a.t_stride;
+  const In *xb, *dfb, *Tb;
   if constexpr (MMA) {
-    xb = reinterpret_cast<const R *>(mv + kMV);
-    dfb = reinterpret_cast<const R *>(mv + 8 * kMV);
-    Tb = reinterpret_cast<const R *>(mv + 8 * kMV + 18);
+    xb = mv + kMV;
+    dfb = mv + 8 * kMV;
+    Tb = mv + 8 * kMV + 18;
+  } else {
+    xb = xsrc + (size_t)b0 * n + tl * n;      // this lane's trajectory (b0: wave-uniform)
+    dfb = a.Df + (size_t)b0 * 18 + tl * 18;
+    Tb = a.T + (size_t)b0 * a.t_stride + tl * a.t_stride;
   }
-  const R T = Tb[s];
+  const R T = (R)Tb[s];
   // axis 0: the (p, v, a) triple at the segment's start and at its end; the other axes are one per-lane stride
   // further (6 within Df, 3m-3 within x: :182-187)
   const bool first = s == 0, last = s + 1 == m;
-  const R *p0 = first ? dfb : xb + 3 * (s - 1);
-  const R *p1 = last ? dfb + 3 : xb + 3 * s;
+  const In *p0 = first ? dfb : xb + 3 * (s - 1);
+  const In *p1 = last ? dfb + 3 : xb + 3 * s;
   const int st0 = first ? 6 : ndp, st1 = last ? 6 : ndp;
   R w0[3][3], w1[3][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      w0[k][i] = p0[k * st0 + i];
-      w1[k][i] = p1[k * st1 + i];
+      w0[k][i] = (R)p0[k * st0 + i];
+      w1[k][i] = (R)p1[k * st1 + i];
     }
   }
 
@@ -1200,7 +1206,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     if constexpr (MMA) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
       __builtin_amdgcn_wave_barrier();
-      gtop_mma_update_core(st, mvecs, msc, n, lane, (double)ctot, reinterpret_cast<const double *>(gl));
+      gtop_mma_update_core(st, mvecs, msc, n, lane, (double)ctot, static_cast<const R *>(gl));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is rewritten by the next evaluation
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -1241,7 +1247,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       const double fcur = __builtin_bit_cast(double, ((unsigned long long)hi32 << 32) | lo32);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
       __builtin_amdgcn_wave_barrier();
-      gtop_mma_update_core(st, mvecs, msc, n, lane, fcur, reinterpret_cast<const double *>(gl));
+      gtop_mma_update_core(st, mvecs, msc, n, lane, fcur, static_cast<const R *>(gl));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is rewritten by the next evaluation
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -1392,9 +1398,14 @@ static hipError_t launch_wave(const GtopKernelArgs<R> &args, const MM &st, const
   const bool colli = !((wa.wc < (R)0 ? -wa.wc : wa.wc) < (R)1e-4);   // :346
   dyn = dyn && wa.step == 2;        // the commented-out block's own test (:383)
   const bool wide = !gtop_field_is_narrow(wa.nx, wa.ny, wa.nz, sizeof(R));
-  const WaveKernelFn<R, MM> kern = wide ? pick_geometry<R, true, MM>(plan, wa.B, colli, dyn)
-                                        : pick_geometry<R, false, MM>(plan, wa.B, colli, dyn);
-  const size_t smem = wave_lds_bytes(plan, wa.m, sizeof(R), MMA);
+  WaveKernelFn<R, MM> kern;
+  if constexpr (MMA && sizeof(R) == 4) {   // (the optimizer loop with fp32 evaluations: no 64-bit-index bodies — a field past 4 GiB in fp32)
+    if (wide) return hipErrorInvalidValue;
+    kern = pick_geometry<R, false, MM>(plan, wa.B, colli, dyn);
+  } else {
+    kern = wide ? pick_geometry<R, true, MM>(plan, wa.B, colli, dyn) : pick_geometry<R, false, MM>(plan, wa.B, colli, dyn);
+  }
+  const size_t smem = wave_lds_bytes(plan, wa.m, MMA ? sizeof(double) : sizeof(R), MMA);   // (the optimizer's state is fp64)
   if (smem > 160u * 1024u) return hipErrorInvalidValue;
   if (smem > 64u * 1024u) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1434,6 +1445,13 @@ hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMm
                                 bool dyn, hipStream_t stream) {
   if (plan.nt != 1 || plan.nw != 1) return hipErrorInvalidValue;
   return launch_wave<double, GtopMmaState>(args, st, plan, dyn, stream);
+}
+// the same loop with the evaluations in fp32 on the fp32 field: args.Df / args.T still point at fp64 rows (the state,
+// the bounds, the update and the results are fp64; see the kernel's `In`), args.x / cost / grad are not read
+hipError_t gtop_launch_eval_mma(const GtopKernelArgs<float> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
+                                bool dyn, hipStream_t stream) {
+  if (plan.nt != 1 || plan.nw != 1) return hipErrorInvalidValue;
+  return launch_wave<float, GtopMmaState>(args, st, plan, dyn, stream);
 }
 
 #ifdef GTOP_STAMPS

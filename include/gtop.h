@@ -410,6 +410,16 @@ int gtop_set_launch_geometry(gtop_ctx *ctx, int waves, int samples_per_lane);
  * 1 = the MMA update runs as the epilogue of the evaluation kernel, one launch
  * per iteration; 0 = separate update launch.  Same arithmetic in all three. */
 int gtop_set_optimizer_fusion(gtop_ctx *ctx, int fused);
+/* Batched optimizer: the arithmetic of its EVALUATIONS.  GTOP_F64 (default) is
+ * the reference's; GTOP_F32 runs them on the fp32 copy of the field in the
+ * packed-fp32 bodies of gtop_eval_device(GTOP_F32) — the trial point, bounds,
+ * Df, T, the CCSA-MMA update and every result stay fp64, so the interface of
+ * gtop_optimize_* does not change.  Measured: 9 % less time for 1 024
+ * trajectories of 6 segments, 17 % for 16 384, 20 % for 65 536.  The iterates
+ * are those of an fp32 objective: an accept / reject decision within fp32's
+ * noise (1e-5 relative) can fall the other way.  Needs a fused launch form
+ * (fusion 1 or 2). */
+int gtop_set_optimizer_precision(gtop_ctx *ctx, int dtype);
 
 #ifdef __cplusplus
 }

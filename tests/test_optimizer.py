@@ -388,3 +388,48 @@ def test_stop_rule_precedence_follows_nlopt(scene, oracle_mod, gtop):
     finally:
         ctx.set_optimizer_fusion(2)
         ctx.set_params()
+
+
+@pytest.mark.parametrize("B,m,fusion", [(300, 6, 2), (300, 6, 1), (200, 9, 2), (64, 17, 2), (4000, 6, 2)])
+def test_optimizer_with_fp32_evaluations(scene, oracle_mod, gtop, B, m, fusion):
+    """gtop_set_optimizer_precision(GTOP_F32): the loop's evaluations on the fp32 field in the fp32 bodies (up to 6
+    segments, 7 .. 12 in packed pairs, the chunked body), its state, update and results fp64.  The objective it
+    minimises is the fp32 one, so its road may part from the fp64 loop's at a decision inside fp32's noise; what must
+    hold: the returned cost IS the callback's value at the returned point (to the fp32 bound), the point is inside
+    its bounds and no worse than the start, evaluation counts and codes as the fp64 loop's, and the batch as a whole
+    gets as far as the fp64 loop does."""
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(B, m, mp, seed=800 + m, step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0))
+    lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+    ctx.set_params()
+    ctx.set_problem(b.T, b.Df)
+    evals = 25
+    x64, c64, n64, code64 = ctx.optimize_batch_ex(b.x, lb, ub, evals)
+    try:
+        ctx.set_optimizer_precision("f32")
+        ctx.set_optimizer_fusion(fusion)
+        x32, c32, n32, code32 = ctx.optimize_batch_ex(b.x, lb, ub, evals)
+        again = ctx.optimize_batch_ex(b.x, lb, ub, evals)
+        ctx.set_optimizer_fusion(0)
+        with pytest.raises(gtop.GtopError):
+            ctx.optimize_batch_ex(b.x, lb, ub, evals)          # the separate-update form is fp64 only
+    finally:
+        ctx.set_optimizer_precision("f64")
+        ctx.set_optimizer_fusion(2)
+    for a, r in zip(again, (x32, c32, n32, code32)):
+        assert np.array_equal(a, r)                              # deterministic
+    assert np.array_equal(n32, n64) and np.array_equal(code32, code64)
+    assert np.all(x32 >= lb - 1e-12) and np.all(x32 <= ub + 1e-12)
+    prm = oracle_mod.make_params()
+    idx = np.arange(B) if B <= 300 else np.r_[0:100, B - 100:B]
+    c_at, _, _ = oracle_mod.eval_batch(b.T[idx], b.Df[idx], x32[idx], sdf, prm, nthreads=8)
+    assert np.max(np.abs(c32[idx] - c_at) / np.abs(c_at)) <= 2e-4           # the fp32 bound of the evaluation
+    c0, _, _ = oracle_mod.eval_batch(b.T[idx], b.Df[idx], b.x[idx], sdf, prm, nthreads=8)
+    assert np.all(c32[idx] <= c0 * (1 + 2e-4))
+    assert 0.8 <= np.median(c32 / c64) <= 1.25, np.median(c32 / c64)
+    ratio32, ratio64 = np.median(c32[idx] / c0), np.median(c64[idx] / c0)
+    assert ratio32 <= max(2 * ratio64, ratio64 + 0.05), (ratio32, ratio64)
+    # the context's fp64 loop is untouched by the excursion
+    back = ctx.optimize_batch_ex(b.x, lb, ub, evals)
+    for a, r in zip(back, (x64, c64, n64, code64)):
+        assert np.array_equal(a, r)

@@ -26,19 +26,21 @@ for B in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384]:
     T = torch.tensor(b.T, device=dev)
     lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
     x0 = torch.tensor(b.x, device=dev)
-    for spl in (0, 3, 6):
-        for mode in (2, 1):
+    for spl, mode, prec in ((0, 2, "f64"), (0, 2, "f64"), (0, 2, "f32"), (0, 1, "f64"), (0, 1, "f32"), (6, 2, "f64")):
+        if True:
             ctx.set_launch_geometry(0, spl)
             ctx.set_optimizer_fusion(mode)
+            ctx.set_optimizer_precision(prec)
             ts = []
             for evals in (50, 100):
-                x = x0.clone()
-                ctx.optimize_device(x, Df, T, lbt, ubt, evals)
-                torch.cuda.synchronize()
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < 0.04:      # sustained clocks (tools/clock_ramp.py)
+                    ctx.optimize_device(x0.clone(), Df, T, lbt, ubt, evals)
+                    torch.cuda.synchronize()
                 x = x0.clone()
                 t0 = time.perf_counter()
                 ctx.optimize_device(x, Df, T, lbt, ubt, evals)
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
-            print(f"B={B} spl={spl} mode={mode}: 50 evals {ts[0]*1e3:.3f} ms, 100 evals {ts[1]*1e3:.3f} ms, "
+            print(f"B={B} spl={spl} mode={mode} {prec}: 50 evals {ts[0]*1e3:.3f} ms, 100 evals {ts[1]*1e3:.3f} ms, "
                   f"slope {(ts[1]-ts[0])/50*1e6:.2f} us/eval-round", flush=True)
