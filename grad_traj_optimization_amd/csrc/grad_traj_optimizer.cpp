@@ -226,6 +226,7 @@ bool GradTrajOptimizer::optimizeTrajectory(int step) {
     const gtop_stop stop = {opt.maxeval > 0 ? opt.maxeval : (1 << 24), 0.0, 0.0, opt.maxtime};
     double minf = 0.0;
     int32_t nev = 0, code = 0;
+    gtop_set_optimizer_precision(ctx_, cfg_.optimizer_fp32 ? GTOP_F32 : GTOP_F64);
     last_status_ = gtop_optimize_batch_ex(ctx_, 1, x.data(), lb.data(), ub.data(), &stop, &minf, &nev, &code);
     last_evals_ = nev;
   } else {
@@ -343,6 +344,8 @@ bool GradTrajBatch::optimizeTrajectories(int step) {
   p.step = step;
   p.enable_dyn = cfg_.enable_dyn;
   if ((last_status_ = gtop_group_set_params(grp_, &p)) != GTOP_OK) return true;
+  for (int i = 0; i < gtop_group_size(grp_); ++i)
+    gtop_set_optimizer_precision(gtop_group_context(grp_, i), cfg_.optimizer_fp32 ? GTOP_F32 : GTOP_F64);
   const double maxtime = step == OPT_FIRST_STEP ? cfg_.time_limit_1 : (step == OPT_SECOND_STEP ? cfg_.time_limit_2 : 0.0);
   const gtop_stop stop = {cfg_.max_evals > 0 ? cfg_.max_evals : (1 << 24), 0.0, 0.0, maxtime};   // :144-148
   // one device problem per distinct segment count, in rising order; each is the whole optimisation of its

@@ -66,6 +66,9 @@ class GradTrajOptimizer {
     // 1: the whole optimisation is ONE launch of the batched device optimizer (gtop_optimize_batch_ex, same
     // algorithm, same stop rules); only the evaluation count is reported, the cost curve stays empty.
     int optimize_on_device = 0;
+    // the device optimizer's evaluations in fp32 (gtop_set_optimizer_precision; its state and results stay fp64):
+    // for large batches through GradTrajBatch; needs the device optimizer (optimize_on_device, or GradTrajBatch)
+    int optimizer_fp32 = 0;
   };
 
   GradTrajOptimizer();

@@ -4,8 +4,9 @@
 // GradTrajOptimizer per trajectory (optimize_on_device: the single-problem form of the same loop).  Prints one JSON
 // object that tests/test_gpu_group.py checks.
 //
-//   gtop_batch_devices <scene.txt> <B> <max_evals> <device> [<device> ...] [ragged]
+//   gtop_batch_devices <scene.txt> <B> <max_evals> <device> [<device> ...] [ragged] [fp32]
 // ragged: every third copy loses one interior waypoint, every third two — three segment counts in one batch.
+// fp32: the optimizer's evaluations in fp32 (Config::optimizer_fp32), in the batch and in the single-problem objects.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,14 +49,16 @@ int main(int argc, char **argv) {
   }
   const int B = std::atoi(argv[2]);
   std::vector<int> devices;
-  bool ragged = false;
+  bool ragged = false, fp32 = false;
   for (int i = 4; i < argc; ++i) {
     if (std::string(argv[i]) == "ragged") ragged = true;
+    else if (std::string(argv[i]) == "fp32") fp32 = true;
     else devices.push_back(std::atoi(argv[i]));
   }
   GradTrajOptimizer::Config cfg;
   cfg.max_evals = std::atoi(argv[3]);
   cfg.time_limit_2 = 30.0;   // evaluation-capped: reproducible
+  cfg.optimizer_fp32 = fp32;  // (the single-problem objects below run the same loop: same bits)
   std::vector<std::vector<Vec3>> lists(B, waypoints);
   for (int b = 0; b < B; ++b)
     for (size_t i = 1; i + 1 < waypoints.size(); ++i) lists[b][i][0] += 0.01 * (b % 17) - 0.05 * ((b / 17) % 3);

@@ -172,3 +172,22 @@ def test_group_walks_through_problems_of_different_sizes(scene, gtop):
                 assert np.array_equal(a, r), (k, B, m)
     ctx.update_sdf_map(mp.obstacle_points())     # (the module's scene as the other tests expect it)
     g.close()
+
+
+def test_cpp_batch_class_with_fp32_evaluations(tmp_path):
+    """Config::optimizer_fp32 through GradTrajBatch (every member context) and through single GradTrajOptimizer objects:
+    the same loop on the same rows, so the batch's minima and coefficients are the objects' (the final cost is
+    re-evaluated in fp64 by costFunc: equal to the fp32 bound)."""
+    import json
+    import os
+    import subprocess
+    from tests import scenes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "grad_traj_optimization_amd", "gtop_batch_devices")
+    f = scenes.write_scene(tmp_path / "opti_node.txt", scenes.OPTI_NODE_MAP_SIZE, scenes.OPTI_NODE_ORIGIN,
+                           scenes.OPTI_NODE_RES, scenes.opti_node_obstacles(), scenes.OPTI_NODE_PATH)
+    out = subprocess.run([exe, str(f), "60", "20", "0", "0", "fp32"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    r = json.loads(out.stdout[out.stdout.index("{"):])
+    assert r["B"] == 60 and r["min_evals"] == r["max_evals"] == 20
+    assert r["max_rel_cost_diff"] <= 2e-4 and r["max_coeff_diff"] <= 1e-9, r
