@@ -17,10 +17,11 @@ pytestmark = pytest.mark.gpu
 TOL64, TOL32 = 1e-5, 2e-4
 # a longer hunt on demand: GTOP_FUZZ_EXTRA=N appends N further seeds to every randomised test of this file
 EXTRA = int(os.environ.get("GTOP_FUZZ_EXTRA", "0"))
+BASE = int(os.environ.get("GTOP_FUZZ_BASE", "100000"))      # (>= 100000: where the extra seeds start)
 
 
 def seeds(first, count):
-    return list(range(first, first + count)) + list(range(100_000 + first, 100_000 + first + EXTRA))
+    return list(range(first, first + count)) + list(range(BASE + first, BASE + first + EXTRA))
 
 
 def _draw(seed):
@@ -145,9 +146,9 @@ def test_random_draw_fp32(gtop, oracle_mod, seed):
     # The interpolant is continuous across voxel cells, its gradient is not: a sample whose position lies within fp32's
     # rounding of a cell face (about 1e-5 of them) takes the neighbouring cell's gradient — the cost agrees to 1e-6, the
     # row's gradient differs by that sample's weight (seen in 65 of 3 040 draws, up to 0.2 of the row's largest entry).
-    # So: every row's cost, and 97 % of the rows' gradients, within the bound.
+    # So: every row's cost, and 95 % of the rows' gradients (a row of 40 segments has 1 200 samples), within the bound.
     _compare(c[fits], g[fits], c_ref[fits], g_ref[fits], tol, ("f32", seed, m, len(bb.x), kw), gfloor=1e-2,
-             grad_rows=0.97 if fits.sum() >= 34 else (fits.sum() - 1.0) / fits.sum())
+             grad_rows=0.95 if fits.sum() >= 40 else (fits.sum() - 2.0) / fits.sum())
     ctx.close()
 
 
