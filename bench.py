@@ -363,8 +363,19 @@ def main():
     # ---- timed region: exactly K = nbuckets*G steps ----
     short = args.steps < 500     # one or two graph launches: every event record inside is ~5 % of the region
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start_at = None
+    if collective:
+        # Ranks leave a barrier tens of microseconds apart, and the region's collective charges the last one's lateness
+        # to everybody (a fifth of a 0.1 ms region).  So the ranks of this node agree — before the barrier — on an instant
+        # shortly after it (CLOCK_MONOTONIC is one clock for all processes of a node) and start there, together.
+        tt0 = torch.tensor([time.perf_counter() + 0.003], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.broadcast(tt0, 0)
+        start_at = float(tt0.item())
     barrier()
     torch.cuda.synchronize()
+    if start_at is not None and 0.0 < start_at - time.perf_counter() < 0.01:   # (another node's clock, a slow barrier: start now)
+        while time.perf_counter() < start_at:
+            pass
     t0 = time.perf_counter()
     if not short:
         ev0.record(stream)
