@@ -329,12 +329,14 @@ int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_ti
   const int per = (B + n - 1) / n;
   g->have_problem = false;
   g->x_resident = false;
+  // nothing of the previous problem may still be running on the buffers about to be reused or replaced — a member's
+  // own work, or another member's copies into its gathered rows
+  if (int rc0 = sync_all(g)) return rc0;
   for (int i = 0; i < n; ++i) {
     Member &mb = g->mem[i];
     mb.first = std::min(B, i * per);
     mb.count = std::min(B, mb.first + per) - mb.first;
     GHIP(g, hipSetDevice(mb.device));
-    GHIP(g, hipStreamSynchronize(mb.stream));   // (nothing of the previous problem may still be running on these buffers)
     // slices padded to `per` rows (RCCL's all-gather sends equal counts); the padding is never read as a result
     GHIP(g, ensure(mb.x, mb.cap[0], (size_t)per * nvar * sizeof(double)));
     GHIP(g, ensure(mb.Df, mb.cap[1], (size_t)per * 18 * sizeof(double)));
