@@ -138,6 +138,7 @@ def load_library():
         "gtop_group_context": (vp, [vp, C.c_int]),
         "gtop_group_last_error": (C.c_char_p, [vp]),
         "gtop_group_gather_backend": (C.c_char_p, [vp]),
+        "gtop_group_gather_note": (C.c_char_p, [vp]),
         "gtop_group_set_params": (C.c_int, [vp, C.POINTER(GtopParams)]),
         "gtop_group_init_sdf_map": (C.c_int, [vp, dp, dp, C.c_double]),
         "gtop_group_update_sdf_map": (C.c_int, [vp, dp, C.c_int]),
@@ -563,7 +564,7 @@ class GtopGroup:
         h = C.c_void_p()
         rc = self._L.gtop_group_create(C.byref(h), devs, len(devices))
         if rc != 0:
-            raise GtopError(rc, "gtop_group_create: " + self._L.gtop_last_error(None).decode())
+            raise GtopError(rc, self._L.gtop_group_last_error(None).decode())
         self._h = h
         self.devices = [int(d) for d in devices]
         self.set_params(**(params or {}))
@@ -586,6 +587,10 @@ class GtopGroup:
     @property
     def gather_backend(self):
         return self._L.gtop_group_gather_backend(self._h).decode()
+
+    def gather_note(self):
+        """The backend and why: a fallback from RCCL to peer copies names its reason."""
+        return self._L.gtop_group_gather_note(self._h).decode()
 
     def set_params(self, **kw):
         d = dict(OPTI_NODE_PARAMS)

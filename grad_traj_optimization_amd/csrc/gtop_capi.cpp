@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "gtop.h"
+#include "gtop_guard.h"
 #include "gtop_kernels.h"
 
 #define GTOP_ABI_VERSION 1
@@ -94,6 +95,16 @@ int fail(gtop_ctx *c, int code, const std::string &msg) {
   else g_create_err = msg;
   return code;
 }
+
+// what an exception caught at the boundary leaves behind (gtop_guard.h); must not throw itself
+void note_exception(gtop_ctx *c, const char *what) noexcept {
+  try {
+    fail(c, GTOP_ERR_INTERNAL, std::string("exception caught at the C boundary: ") + what);
+  } catch (...) {
+  }
+}
+#define GTOP_CATCH_STATUS(c) GTOP_CATCH_WITH(note_exception, c, GTOP_ERR_INTERNAL)
+#define GTOP_CATCH_HUGE(c) GTOP_CATCH_WITH(note_exception, c, HUGE_VAL)
 
 #define HIPCHK(ctx, call)                                                              \
   do {                                                                                 \
@@ -229,7 +240,7 @@ extern "C" {
 
 int gtop_abi_version(void) { return GTOP_ABI_VERSION; }
 
-int gtop_create(gtop_ctx **out, int device) {
+int gtop_create(gtop_ctx **out, int device) try {
   if (!out) return fail(nullptr, GTOP_ERR_INVALID, "gtop_create: out is NULL");
   *out = nullptr;
   int ndev = 0;
@@ -257,9 +268,9 @@ int gtop_create(gtop_ctx **out, int device) {
   }
   *out = c;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(nullptr)
 
-int gtop_destroy(gtop_ctx *c) {
+int gtop_destroy(gtop_ctx *c) try {
   if (!c) return GTOP_ERR_INVALID;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -273,11 +284,11 @@ int gtop_destroy(gtop_ctx *c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 const char *gtop_last_error(const gtop_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
-int gtop_set_params(gtop_ctx *c, const gtop_params *p) {
+int gtop_set_params(gtop_ctx *c, const gtop_params *p) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!p) return fail(c, GTOP_ERR_INVALID, "params is NULL");
   if (p->step < 0 || p->step > 2)   // grad_traj_optimizer.cpp:129-131
@@ -288,10 +299,10 @@ int gtop_set_params(gtop_ctx *c, const gtop_params *p) {
   c->prm = *p;
   c->have_params = true;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_set_sdf(gtop_ctx *c, const double *dist_host, int nx, int ny, int nz,
-                 const double origin[3], const double *map_size, double resolution) {
+                 const double origin[3], const double *map_size, double resolution) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!dist_host) return fail(c, GTOP_ERR_INVALID, "dist_host is NULL");
   HIPCHK(c, hipSetDevice(c->device));
@@ -304,10 +315,10 @@ int gtop_set_sdf(gtop_ctx *c, const double *dist_host, int nx, int ny, int nz,
   c->sdf32_stale = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_set_sdf_device(gtop_ctx *c, int dtype, const void *dist_dev, int nx, int ny, int nz,
-                        const double origin[3], const double *map_size, double resolution) {
+                        const double origin[3], const double *map_size, double resolution) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!dist_dev) return fail(c, GTOP_ERR_INVALID, "dist_dev is NULL");
   if (dtype != GTOP_F64 && dtype != GTOP_F32) return fail(c, GTOP_ERR_INVALID, "bad dtype");
@@ -320,9 +331,9 @@ int gtop_set_sdf_device(gtop_ctx *c, int dtype, const void *dist_dev, int nx, in
   else
     c->sdf32 = const_cast<float *>(static_cast<const float *>(dist_dev));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_init_sdf_map(gtop_ctx *c, const double map_size[3], const double origin[3], double resolution) {
+int gtop_init_sdf_map(gtop_ctx *c, const double map_size[3], const double origin[3], double resolution) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!map_size || !origin || !(resolution > 0.0))
     return fail(c, GTOP_ERR_INVALID, "initSDFMap: need map_size, origin, resolution > 0");
@@ -340,7 +351,7 @@ int gtop_init_sdf_map(gtop_ctx *c, const double map_size[3], const double origin
   c->sdf32_stale = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 // the build proper: obstacle points already in HBM, launches on `s`, no synchronisation
 static int update_sdf_map_on_stream(gtop_ctx *c, const double *d_pts, int npts, hipStream_t s, bool convert_now) {
@@ -366,7 +377,7 @@ static int update_sdf_map_on_stream(gtop_ctx *c, const double *d_pts, int npts, 
   return GTOP_OK;
 }
 
-int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
+int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) try {
   if (!c) return GTOP_ERR_INVALID;
   if (npts < 0 || (npts > 0 && !pts)) return fail(c, GTOP_ERR_INVALID, "bad obstacle list");
   if (!c->have_grid || !c->own64 || !c->occ)
@@ -380,9 +391,9 @@ int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) {
   if ((rc = update_sdf_map_on_stream(c, c->d_pts, npts, c->stream, /*convert_now=*/false))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_update_sdf_map_device(gtop_ctx *c, const void *d_pts, int npts, void *hip_stream) {
+int gtop_update_sdf_map_device(gtop_ctx *c, const void *d_pts, int npts, void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   if (npts < 0 || (npts > 0 && !d_pts)) return fail(c, GTOP_ERR_INVALID, "bad obstacle list");
   if (!c->have_grid || !c->own64 || !c->occ)
@@ -390,9 +401,9 @@ int gtop_update_sdf_map_device(gtop_ctx *c, const void *d_pts, int npts, void *h
   HIPCHK(c, hipSetDevice(c->device));
   return update_sdf_map_on_stream(c, static_cast<const double *>(d_pts), npts, static_cast<hipStream_t>(hip_stream),
                                   /*convert_now=*/true);
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_get_sdf(gtop_ctx *c, double *dist_host, int grid_out[3]) {
+int gtop_get_sdf(gtop_ctx *c, double *dist_host, int grid_out[3]) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!c->have_grid || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
   HIPCHK(c, hipSetDevice(c->device));
@@ -404,10 +415,10 @@ int gtop_get_sdf(gtop_ctx *c, double *dist_host, int grid_out[3]) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_set_problem(gtop_ctx *c, int B, int m, const double *segment_time, int time_stride,
-                     const double *Df) {
+                     const double *Df) try {
   if (!c) return GTOP_ERR_INVALID;
   if (B < 1 || m < 2 || !segment_time || !Df || (time_stride != 0 && time_stride != m))
     return fail(c, GTOP_ERR_INVALID, "set_problem: need B >= 1, m >= 2, time_stride in {0, m}");
@@ -427,9 +438,9 @@ int gtop_set_problem(gtop_ctx *c, int B, int m, const double *segment_time, int 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->B = B; c->m = m; c->t_stride = time_stride;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *grad) {
+int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *grad) try {
   if (!c) return GTOP_ERR_INVALID;
   int rc = check_eval_state(c);
   if (rc) return rc;
@@ -505,9 +516,9 @@ int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *g
   HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-double gtop_cost_nlopt(unsigned n, const double *x, double *grad, void *vctx) {
+double gtop_cost_nlopt(unsigned n, const double *x, double *grad, void *vctx) try {
   gtop_ctx *c = static_cast<gtop_ctx *>(vctx);
   if (!c) return HUGE_VAL;
   const auto tb1 = std::chrono::steady_clock::now();
@@ -533,10 +544,10 @@ double gtop_cost_nlopt(unsigned n, const double *x, double *grad, void *vctx) {
   else
     c->vec_cost.push_back(c->vec_cost.back());
   return cost;
-}
+} GTOP_CATCH_HUGE(static_cast<gtop_ctx *>(vctx))
 
 int gtop_eval_device(gtop_ctx *c, int dtype, int B, int m, const void *d_x, const void *d_Df,
-                     const void *d_T, int time_stride, void *d_cost, void *d_grad, void *hip_stream) {
+                     const void *d_T, int time_stride, void *d_cost, void *d_grad, void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   int rc = check_eval_state(c);
   if (rc) return rc;
@@ -562,11 +573,11 @@ int gtop_eval_device(gtop_ctx *c, int dtype, int B, int m, const void *d_x, cons
     return launch_eval<float>(c, c->sdf32, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
   }
   return fail(c, GTOP_ERR_INVALID, "bad dtype");
-}
+} GTOP_CATCH_STATUS(c)
 
 // ---- setup (f3) and post-processing (f4) ----
 int gtop_setup_paths_device(gtop_ctx *c, int B, int m, const void *d_wp, double mean_v, double init_time,
-                            void *d_T, void *d_Df, void *d_x0, void *hip_stream) {
+                            void *d_T, void *d_Df, void *d_x0, void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   if (B < 0 || m < 2 || !(mean_v > 0.0)) return fail(c, GTOP_ERR_INVALID, "setup_paths: need B >= 0, m >= 2, mean_v > 0");
   if (B == 0) return GTOP_OK;
@@ -576,10 +587,10 @@ int gtop_setup_paths_device(gtop_ctx *c, int B, int m, const void *d_wp, double 
                                     static_cast<double *>(d_T), static_cast<double *>(d_Df),
                                     static_cast<double *>(d_x0), static_cast<hipStream_t>(hip_stream)));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_set_paths(gtop_ctx *c, int B, int m, const double *waypoints, double mean_v, double init_time,
-                   double *x0) {
+                   double *x0) try {
   if (!c) return GTOP_ERR_INVALID;
   if (B < 1 || m < 2 || !waypoints || !(mean_v > 0.0))
     return fail(c, GTOP_ERR_INVALID, "set_paths: need B >= 1, m >= 2 (3+ waypoints), mean_v > 0");
@@ -608,9 +619,9 @@ int gtop_set_paths(gtop_ctx *c, int B, int m, const double *waypoints, double me
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->B = B; c->m = m; c->t_stride = m;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_get_problem(gtop_ctx *c, double *segment_time, double *Df) {
+int gtop_get_problem(gtop_ctx *c, double *segment_time, double *Df) try {
   if (!c) return GTOP_ERR_INVALID;
   if (c->B == 0) return fail(c, GTOP_ERR_STATE, "no problem set");
   HIPCHK(c, hipSetDevice(c->device));
@@ -620,10 +631,10 @@ int gtop_get_problem(gtop_ctx *c, double *segment_time, double *Df) {
   if (Df) HIPCHK(c, hipMemcpyAsync(Df, c->d_Df, (size_t)c->B * 18 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_coefficients_device(gtop_ctx *c, int B, int m, const void *d_x, const void *d_Df, const void *d_T,
-                             int time_stride, void *d_coeff, void *hip_stream) {
+                             int time_stride, void *d_coeff, void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   if (B < 0 || m < 2 || (time_stride != 0 && time_stride != m))
     return fail(c, GTOP_ERR_INVALID, "coefficients: need B >= 0, m >= 2, time_stride in {0, m}");
@@ -634,11 +645,11 @@ int gtop_coefficients_device(gtop_ctx *c, int B, int m, const void *d_x, const v
                                      static_cast<const double *>(d_T), time_stride, static_cast<double *>(d_coeff),
                                      static_cast<hipStream_t>(hip_stream)));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_sample_trajectories_device(gtop_ctx *c, int B, int m, const void *d_coeff, const void *d_T, int time_stride,
                                     double dt_sample, void *d_stats, void *d_samples, int max_samples,
-                                    void *hip_stream) {
+                                    void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   if (B < 0 || m < 1 || !(dt_sample > 0.0) || (time_stride != 0 && time_stride != m) || max_samples < 0)
     return fail(c, GTOP_ERR_INVALID, "eval_trajectories: need B >= 0, m >= 1, dt_sample > 0, time_stride in {0, m}");
@@ -650,19 +661,19 @@ int gtop_sample_trajectories_device(gtop_ctx *c, int B, int m, const void *d_coe
                                           max_samples > 0 ? static_cast<double *>(d_samples) : nullptr, max_samples,
                                           static_cast<hipStream_t>(hip_stream)));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_eval_trajectories_device(gtop_ctx *c, int B, int m, const void *d_coeff, const void *d_T, int time_stride,
-                                  double dt_sample, void *d_stats, void *hip_stream) {
+                                  double dt_sample, void *d_stats, void *hip_stream) try {
   return gtop_sample_trajectories_device(c, B, m, d_coeff, d_T, time_stride, dt_sample, d_stats, nullptr, 0, hip_stream);
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_trajectory_stats(gtop_ctx *c, int B, const double *x, double dt_sample, double *coeff, double *stats) {
+int gtop_trajectory_stats(gtop_ctx *c, int B, const double *x, double dt_sample, double *coeff, double *stats) try {
   return gtop_trajectory_samples(c, B, x, dt_sample, coeff, stats, nullptr, 0);
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_trajectory_samples(gtop_ctx *c, int B, const double *x, double dt_sample, double *coeff, double *stats,
-                            double *samples, int max_samples) {
+                            double *samples, int max_samples) try {
   if (!c) return GTOP_ERR_INVALID;
   if (c->B == 0) return fail(c, GTOP_ERR_STATE, "gtop_set_problem / gtop_set_paths has not been called");
   if (B < 1 || B > c->B || !x || (!coeff && !stats && !samples) || max_samples < 0 || (samples && max_samples == 0))
@@ -690,9 +701,9 @@ int gtop_trajectory_samples(gtop_ctx *c, int B, const double *x, double dt_sampl
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_set_moving_boxes(gtop_ctx *c, int nbox, const double *p0, const double *vel, const double *scale) {
+int gtop_set_moving_boxes(gtop_ctx *c, int nbox, const double *p0, const double *vel, const double *scale) try {
   if (!c) return GTOP_ERR_INVALID;
   if (nbox < 0 || (nbox > 0 && (!p0 || !vel || !scale))) return fail(c, GTOP_ERR_INVALID, "set_moving_boxes: bad box list");
   HIPCHK(c, hipSetDevice(c->device));
@@ -707,10 +718,10 @@ int gtop_set_moving_boxes(gtop_ctx *c, int nbox, const double *p0, const double 
   HIPCHK(c, hipStreamSynchronize(c->stream));   // the host arrays may go away
   c->nbox = nbox;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_edt_query_device(gtop_ctx *c, int N, const void *d_pos, const void *d_time, void *d_dist, void *d_grad,
-                          void *hip_stream) {
+                          void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!c->have_grid || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
   if (N < 0) return fail(c, GTOP_ERR_INVALID, "edt_query: N < 0");
@@ -723,9 +734,9 @@ int gtop_edt_query_device(gtop_ctx *c, int N, const void *d_pos, const void *d_t
                                   static_cast<double *>(d_dist), static_cast<double *>(d_grad),
                                   static_cast<hipStream_t>(hip_stream)));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_edt_query(gtop_ctx *c, int N, const double *pos, const double *time, double *dist, double *grad) {
+int gtop_edt_query(gtop_ctx *c, int N, const double *pos, const double *time, double *dist, double *grad) try {
   if (!c) return GTOP_ERR_INVALID;
   if (N < 0 || (N > 0 && (!pos || !time || !dist || !grad))) return fail(c, GTOP_ERR_INVALID, "edt_query: bad arguments");
   if (N == 0) return GTOP_OK;
@@ -741,11 +752,11 @@ int gtop_edt_query(gtop_ctx *c, int N, const double *pos, const double *time, do
   HIPCHK(c, hipMemcpyAsync(grad, dg, 3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 // EDTEnvironment::evaluateCoarseEDT (src/edt_environment.cpp:124-136)
 int gtop_edt_coarse_query_device(gtop_ctx *c, int N, const void *d_pos, const void *d_time, void *d_dist,
-                                 void *hip_stream) {
+                                 void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!c->have_grid || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
   if (N < 0) return fail(c, GTOP_ERR_INVALID, "edt_coarse_query: N < 0");
@@ -757,9 +768,9 @@ int gtop_edt_coarse_query_device(gtop_ctx *c, int N, const void *d_pos, const vo
                                   static_cast<const double *>(d_pos), static_cast<const double *>(d_time),
                                   static_cast<double *>(d_dist), nullptr, static_cast<hipStream_t>(hip_stream)));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_edt_coarse_query(gtop_ctx *c, int N, const double *pos, const double *time, double *dist) {
+int gtop_edt_coarse_query(gtop_ctx *c, int N, const double *pos, const double *time, double *dist) try {
   if (!c) return GTOP_ERR_INVALID;
   if (N < 0 || (N > 0 && (!pos || !time || !dist))) return fail(c, GTOP_ERR_INVALID, "edt_coarse_query: bad arguments");
   if (N == 0) return GTOP_OK;
@@ -774,14 +785,14 @@ int gtop_edt_coarse_query(gtop_ctx *c, int N, const double *pos, const double *t
   HIPCHK(c, hipMemcpyAsync(dist, dd, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 // Batched optimizer: max_evals rounds of {cost/gradient, MMA update} per trajectory on
 // `stream` — one launch for the whole loop (fusion mode 2), one per round (1), or two
 // per round (0); no host synchronisation inside.
 int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df, const void *d_T,
                             int time_stride, const void *d_lb, const void *d_ub, const gtop_stop *stop, void *d_minf,
-                            int32_t *d_nevals, int32_t *d_code, void *hip_stream) {
+                            int32_t *d_nevals, int32_t *d_code, void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   int rc = check_eval_state(c);
   if (rc) return rc;
@@ -888,18 +899,18 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   if (d_minf) HIPCHK(c, hipMemcpyAsync(d_minf, st.minf, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s));
   HIPCHK(c, gtop_launch_mma_finish(st, B, d_code, d_nevals, s));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_optimize_device(gtop_ctx *c, int B, int m, void *d_x, const void *d_Df, const void *d_T,
                          int time_stride, const void *d_lb, const void *d_ub, int max_evals, void *d_minf,
-                         void *hip_stream) {
+                         void *hip_stream) try {
   const gtop_stop stop = {max_evals, 0.0, 0.0, 0.0};
   return gtop_optimize_device_ex(c, B, m, d_x, d_Df, d_T, time_stride, d_lb, d_ub, &stop, d_minf, nullptr, nullptr,
                                  hip_stream);
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_optimize_batch_ex(gtop_ctx *c, int B, double *x, const double *lb, const double *ub, const gtop_stop *stop,
-                           double *min_cost, int32_t *nevals, int32_t *code) {
+                           double *min_cost, int32_t *nevals, int32_t *code) try {
   if (!c) return GTOP_ERR_INVALID;
   if (c->B == 0) return fail(c, GTOP_ERR_STATE, "gtop_set_problem has not been called");
   if (B < 1 || B > c->B || !x || !lb || !ub || !stop)
@@ -925,13 +936,13 @@ int gtop_optimize_batch_ex(gtop_ctx *c, int B, double *x, const double *lb, cons
     HIPCHK(c, hipMemcpyAsync(code, c->mma_res + B, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_optimize_batch(gtop_ctx *c, int B, double *x, const double *lb, const double *ub, int max_evals,
-                        double *min_cost) {
+                        double *min_cost) try {
   const gtop_stop stop = {max_evals, 0.0, 0.0, 0.0};
   return gtop_optimize_batch_ex(c, B, x, lb, ub, &stop, min_cost, nullptr, nullptr);
-}
+} GTOP_CATCH_STATUS(c)
 
 // grad_traj_optimizer.cpp:151-179
 int gtop_default_bounds(int B, int m, const double *path, double bos, double vos, double aos, double *lb,
@@ -967,12 +978,12 @@ int gtop_get_stats(const gtop_ctx *c, int64_t *iter_num, double *total_time) {
   return GTOP_OK;
 }
 
-int gtop_reset_stats(gtop_ctx *c) {
+int gtop_reset_stats(gtop_ctx *c) try {
   if (!c) return GTOP_ERR_INVALID;
   c->iter_num = 0;
   c->total_time = 0.0;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 int gtop_get_cost_curve(const gtop_ctx *c, double *cost, double *time, int cap, int *count) {
   if (!c) return GTOP_ERR_INVALID;
@@ -986,29 +997,29 @@ int gtop_get_cost_curve(const gtop_ctx *c, double *cost, double *time, int cap, 
   return GTOP_OK;
 }
 
-int gtop_clear_cost_curve(gtop_ctx *c) {
+int gtop_clear_cost_curve(gtop_ctx *c) try {
   if (!c) return GTOP_ERR_INVALID;
   c->vec_cost.clear();   // grad_traj_optimizer.cpp:192-194
   c->vec_time.clear();
   c->time_start = std::chrono::steady_clock::now();
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_set_optimizer_fusion(gtop_ctx *c, int fused) {
+int gtop_set_optimizer_fusion(gtop_ctx *c, int fused) try {
   if (!c) return GTOP_ERR_INVALID;
   if (fused < 0 || fused > 2) return fail(c, GTOP_ERR_INVALID, "optimizer fusion mode is 0, 1 or 2");
   c->fuse_mma = fused;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_set_optimizer_precision(gtop_ctx *c, int dtype) {
+int gtop_set_optimizer_precision(gtop_ctx *c, int dtype) try {
   if (!c) return GTOP_ERR_INVALID;
   if (dtype != GTOP_F64 && dtype != GTOP_F32) return fail(c, GTOP_ERR_INVALID, "optimizer precision is GTOP_F64 or GTOP_F32");
   c->opt_dtype = dtype;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
-int gtop_set_launch_geometry(gtop_ctx *c, int waves, int samples_per_lane) {
+int gtop_set_launch_geometry(gtop_ctx *c, int waves, int samples_per_lane) try {
   if (!c) return GTOP_ERR_INVALID;
   // one kernel family: a workgroup is one wavefront; the lanes-per-segment choice is what is left to pin
   if (waves != 0 && waves != 1) return fail(c, GTOP_ERR_INVALID, "waves per workgroup must be 0 (auto) or 1");
@@ -1018,6 +1029,6 @@ int gtop_set_launch_geometry(gtop_ctx *c, int waves, int samples_per_lane) {
                                      "or 6 (five lanes per segment)");
   c->spl = s;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(c)
 
 }  // extern "C"

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "gtop.h"
+#include "gtop_guard.h"
 
 namespace {
 
@@ -87,6 +88,7 @@ struct gtop_group {
   std::string err;
   int B = 0, m = 0, t_stride = 0, per = 0;   // per = rows per slice (the last may hold fewer)
   bool have_problem = false, use_rccl = false, x_resident = false;
+  std::string gather_note;   // why the gather backend is what it is (gtop_group_gather_note)
   Rccl rccl;
 };
 
@@ -96,6 +98,24 @@ int gfail(gtop_group *g, int code, const std::string &msg) {
   if (g) g->err = msg;
   return code;
 }
+
+// error text of a failed gtop_group_create (there is no group to hold it): gtop_group_last_error(NULL) returns it
+thread_local std::string g_group_create_err;
+
+int gfail_create(int code, const std::string &msg) {
+  g_group_create_err = msg;
+  return code;
+}
+
+void note_exception(gtop_group *g, const char *what) noexcept {
+  try {
+    const std::string msg = std::string("exception caught at the C boundary: ") + what;
+    if (g) g->err = msg;
+    else g_group_create_err = msg;
+  } catch (...) {
+  }
+}
+#define GTOP_CATCH_STATUS(g) GTOP_CATCH_WITH(note_exception, static_cast<gtop_group *>(g), GTOP_ERR_INTERNAL)
 
 #define GHIP(g, call)                                                                         \
   do {                                                                                        \
@@ -190,12 +210,13 @@ int sync_all(gtop_group *g) {
 
 extern "C" {
 
-int gtop_group_create(gtop_group **out, const int *devices, int n_devices) {
-  if (!out) return GTOP_ERR_INVALID;
+int gtop_group_create(gtop_group **out, const int *devices, int n_devices) try {
+  if (!out) return gfail_create(GTOP_ERR_INVALID, "gtop_group_create: out is NULL");
   *out = nullptr;
-  if (!devices || n_devices < 1 || n_devices > 64) return GTOP_ERR_INVALID;
+  if (!devices || n_devices < 1 || n_devices > 64)
+    return gfail_create(GTOP_ERR_INVALID, "gtop_group_create: need a device list of 1 .. 64 entries");
   gtop_group *g = new (std::nothrow) gtop_group();
-  if (!g) return GTOP_ERR_INVALID;
+  if (!g) return gfail_create(GTOP_ERR_INTERNAL, "gtop_group_create: out of memory");
   g->mem.resize(n_devices);
   std::set<int> distinct;
   for (int i = 0; i < n_devices; ++i) {
@@ -208,9 +229,12 @@ int gtop_group_create(gtop_group **out, const int *devices, int n_devices) {
     if (rc == GTOP_OK && hipEventCreateWithFlags(&mb.done, hipEventDisableTiming) != hipSuccess) rc = GTOP_ERR_HIP;
     if (rc == GTOP_OK && hipEventCreateWithFlags(&mb.ready, hipEventDisableTiming) != hipSuccess) rc = GTOP_ERR_HIP;
     if (rc != GTOP_OK) {
+      const std::string why = std::string("gtop_group_create: member ") + std::to_string(i) + " (device " +
+                              std::to_string(mb.device) + "): " +
+                              (mb.ctx ? "stream / event creation failed" : gtop_last_error(nullptr));
       gtop_group_destroy(g);
       (void)hipGetLastError();   // (the runtime's error of the failed call must not surface at somebody's next launch)
-      return rc;
+      return gfail_create(rc, why);
     }
   }
   // peers: every pair of different devices that can reach each other directly (the copy path; RCCL finds its own way)
@@ -242,17 +266,24 @@ int gtop_group_create(gtop_group **out, const int *devices, int n_devices) {
     }
     if (!g->use_rccl && force_rccl) {
       gtop_group_destroy(g);
-      return GTOP_ERR_HIP;
+      return gfail_create(GTOP_ERR_HIP, "gtop_group_create: GTOP_GROUP_GATHER=rccl, but " + why);
     }
+    // a silent fallback hides a broken RCCL installation: the reason stays readable (gtop_group_gather_note)
+    g->gather_note = g->use_rccl ? "rccl: one communicator per device (ncclCommInitAll)"
+                                 : "copy: peer copies, because " + why;
   } else if (force_rccl) {
     gtop_group_destroy(g);
-    return GTOP_ERR_INVALID;   // a device listed twice cannot have an RCCL communicator
+    // a device listed twice cannot have an RCCL communicator
+    return gfail_create(GTOP_ERR_INVALID, "gtop_group_create: GTOP_GROUP_GATHER=rccl needs every listed device to be different");
+  } else {
+    g->gather_note = force_copy ? "copy: peer copies, forced by GTOP_GROUP_GATHER=copy"
+                                : "copy: peer copies, because a device is listed more than once (RCCL wants one rank per device)";
   }
   *out = g;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(nullptr)
 
-int gtop_group_destroy(gtop_group *g) {
+int gtop_group_destroy(gtop_group *g) try {
   if (!g) return GTOP_ERR_INVALID;
   for (Member &mb : g->mem) {
     if (!mb.stream) continue;
@@ -271,28 +302,29 @@ int gtop_group_destroy(gtop_group *g) {
   }
   delete g;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(g)
 
 int gtop_group_size(const gtop_group *g) { return g ? (int)g->mem.size() : 0; }
 gtop_ctx *gtop_group_context(gtop_group *g, int i) {
   return (g && i >= 0 && i < (int)g->mem.size()) ? g->mem[i].ctx : nullptr;
 }
-const char *gtop_group_last_error(const gtop_group *g) { return g ? g->err.c_str() : "gtop_group is NULL"; }
+const char *gtop_group_last_error(const gtop_group *g) { return g ? g->err.c_str() : g_group_create_err.c_str(); }
 const char *gtop_group_gather_backend(const gtop_group *g) { return (g && g->use_rccl) ? "rccl" : "copy"; }
+const char *gtop_group_gather_note(const gtop_group *g) { return g ? g->gather_note.c_str() : ""; }
 
-int gtop_group_set_params(gtop_group *g, const gtop_params *p) {
+int gtop_group_set_params(gtop_group *g, const gtop_params *p) try {
   if (!g) return GTOP_ERR_INVALID;
   for (Member &mb : g->mem) GCTX(g, mb, gtop_set_params(mb.ctx, p));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(g)
 
-int gtop_group_init_sdf_map(gtop_group *g, const double map_size[3], const double origin[3], double resolution) {
+int gtop_group_init_sdf_map(gtop_group *g, const double map_size[3], const double origin[3], double resolution) try {
   if (!g) return GTOP_ERR_INVALID;
   for (Member &mb : g->mem) GCTX(g, mb, gtop_init_sdf_map(mb.ctx, map_size, origin, resolution));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(g)
 
-int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts) {
+int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts) try {
   if (!g) return GTOP_ERR_INVALID;
   if (npts < 0 || (npts > 0 && !pts)) return gfail(g, GTOP_ERR_INVALID, "bad obstacle list");
   // replicated: every device builds the field from the same points, all of them at the same time (the upload and the
@@ -311,16 +343,16 @@ int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts) {
     GCTX(g, mb, gtop_update_sdf_map_device(mb.ctx, mb.pts, npts, mb.stream));
   }
   return sync_all(g);
-}
+} GTOP_CATCH_STATUS(g)
 
 int gtop_group_set_sdf(gtop_group *g, const double *dist_host, int nx, int ny, int nz, const double origin[3],
-                       const double *map_size, double resolution) {
+                       const double *map_size, double resolution) try {
   if (!g) return GTOP_ERR_INVALID;
   for (Member &mb : g->mem) GCTX(g, mb, gtop_set_sdf(mb.ctx, dist_host, nx, ny, nz, origin, map_size, resolution));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(g)
 
-int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_time, int time_stride, const double *Df) {
+int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_time, int time_stride, const double *Df) try {
   if (!g) return GTOP_ERR_INVALID;
   if (B < 1 || m < 2 || !segment_time || !Df || (time_stride != 0 && time_stride != m))
     return gfail(g, GTOP_ERR_INVALID, "group set_problem: need B >= 1, m >= 2, time_stride in {0, m}");
@@ -362,7 +394,7 @@ int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_ti
   g->B = B; g->m = m; g->t_stride = time_stride; g->per = per;
   g->have_problem = true;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(g)
 
 int gtop_group_shard(const gtop_group *g, int i, int *first, int *count) {
   if (!g || !g->have_problem || i < 0 || i >= (int)g->mem.size()) return GTOP_ERR_INVALID;
@@ -381,7 +413,7 @@ static int launch_slices(gtop_group *g) {
   return GTOP_OK;
 }
 
-int gtop_group_eval_batch(gtop_group *g, int B, const double *x, double *cost, double *grad) {
+int gtop_group_eval_batch(gtop_group *g, int B, const double *x, double *cost, double *grad) try {
   if (!g) return GTOP_ERR_INVALID;
   if (!g->have_problem) return gfail(g, GTOP_ERR_STATE, "gtop_group_set_problem has not been called");
   if (B != g->B || !x || !cost || !grad) return gfail(g, GTOP_ERR_INVALID, "group eval_batch: B must be the problem's batch");
@@ -403,9 +435,9 @@ int gtop_group_eval_batch(gtop_group *g, int B, const double *x, double *cost, d
   }
   g->x_resident = true;
   return sync_all(g);
-}
+} GTOP_CATCH_STATUS(g)
 
-int gtop_group_upload_x(gtop_group *g, int B, const double *x) {
+int gtop_group_upload_x(gtop_group *g, int B, const double *x) try {
   if (!g) return GTOP_ERR_INVALID;
   if (!g->have_problem) return gfail(g, GTOP_ERR_STATE, "gtop_group_set_problem has not been called");
   if (B != g->B || !x) return gfail(g, GTOP_ERR_INVALID, "group upload_x: B must be the problem's batch");
@@ -418,9 +450,9 @@ int gtop_group_upload_x(gtop_group *g, int B, const double *x) {
   }
   g->x_resident = true;
   return sync_all(g);
-}
+} GTOP_CATCH_STATUS(g)
 
-int gtop_group_eval_resident(gtop_group *g, int gather, int synchronize) {
+int gtop_group_eval_resident(gtop_group *g, int gather, int synchronize) try {
   if (!g) return GTOP_ERR_INVALID;
   if (!g->have_problem || !g->x_resident) return gfail(g, GTOP_ERR_STATE, "group eval_resident: set the problem and upload x first");
   if (gather < 0 || gather > 2) return gfail(g, GTOP_ERR_INVALID, "gather: 0 none, 1 costs, 2 costs and gradients");
@@ -428,11 +460,11 @@ int gtop_group_eval_resident(gtop_group *g, int gather, int synchronize) {
   if (rc) return rc;
   if (gather && (rc = all_gather(g, gather == 2))) return rc;
   return synchronize ? sync_all(g) : GTOP_OK;
-}
+} GTOP_CATCH_STATUS(g)
 
 int gtop_group_synchronize(gtop_group *g) { return g ? sync_all(g) : GTOP_ERR_INVALID; }
 
-int gtop_group_read_gathered(gtop_group *g, int member, double *cost, double *grad) {
+int gtop_group_read_gathered(gtop_group *g, int member, double *cost, double *grad) try {
   if (!g || !g->have_problem || member < 0 || member >= (int)g->mem.size()) return GTOP_ERR_INVALID;
   Member &mb = g->mem[member];
   const size_t nvar = 9 * (size_t)(g->m - 1);
@@ -442,10 +474,10 @@ int gtop_group_read_gathered(gtop_group *g, int member, double *cost, double *gr
     GHIP(g, hipMemcpyAsync(grad, mb.grad_all, (size_t)g->B * nvar * sizeof(double), hipMemcpyDeviceToHost, mb.stream));
   GHIP(g, hipStreamSynchronize(mb.stream));
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(g)
 
 int gtop_group_device_buffers(gtop_group *g, int member, void **d_x, void **d_cost, void **d_grad, void **d_cost_all,
-                              void **d_grad_all, void **hip_stream) {
+                              void **d_grad_all, void **hip_stream) try {
   if (!g || !g->have_problem || member < 0 || member >= (int)g->mem.size()) return GTOP_ERR_INVALID;
   Member &mb = g->mem[member];
   if (d_x) *d_x = mb.x;
@@ -456,10 +488,10 @@ int gtop_group_device_buffers(gtop_group *g, int member, void **d_x, void **d_co
   if (hip_stream) *hip_stream = mb.stream;
   g->x_resident = true;   // the caller writes x where it lives
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(g)
 
 int gtop_group_optimize_batch_ex(gtop_group *g, int B, double *x, const double *lb, const double *ub,
-                                 const gtop_stop *stop, double *min_cost, int32_t *nevals, int32_t *code) {
+                                 const gtop_stop *stop, double *min_cost, int32_t *nevals, int32_t *code) try {
   if (!g) return GTOP_ERR_INVALID;
   if (!g->have_problem) return gfail(g, GTOP_ERR_STATE, "gtop_group_set_problem has not been called");
   if (B != g->B || !x || !lb || !ub || !stop) return gfail(g, GTOP_ERR_INVALID, "group optimize: B must be the problem's batch");
@@ -495,6 +527,6 @@ int gtop_group_optimize_batch_ex(gtop_group *g, int B, double *x, const double *
   }
   g->x_resident = true;
   return sync_all(g);
-}
+} GTOP_CATCH_STATUS(g)
 
 }  // extern "C"

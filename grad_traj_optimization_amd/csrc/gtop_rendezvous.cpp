@@ -41,6 +41,7 @@
 #include <unistd.h>
 
 #include "gtop.h"
+#include "gtop_guard.h"
 
 struct gtop_rendezvous_slot {
   gtop_rendezvous *owner;
@@ -60,15 +61,24 @@ struct gtop_rendezvous {
   std::vector<double> x, cost, grad;   // [n_slots][n], [n_slots], [n_slots][n]
   std::mutex mu;                  // guards the bookkeeping below only: never held across a launch or a sleep
   int active = 0, arrived = 0;
+  bool evaluating = false;        // a leader has been elected and is inside gtop_eval_batch with x / cost / grad
+  std::atomic<int> inside{0};     // threads inside gtop_cost_nlopt_shared / gtop_rendezvous_leave right now
   std::atomic<uint32_t> generation{0};   // waiters sleep on this word (futex)
   int last_status = GTOP_OK;      // of the generation just evaluated
   std::atomic<bool> broken{false};   // gtop_rendezvous_abort, or a waiter's timeout: every call returns HUGE_VAL from then on
   double timeout_s = 0.0;         // longest a caller waits for the others (0 = for ever)
+  double test_delay_s = 0.0;      // diagnostic (GTOP_RENDEZVOUS_TEST_DELAY_MS at create): the leader sleeps this long
+                                  // before its launch, standing in for a slow first launch in the timeout tests
   int64_t launches = 0;
   double launch_seconds = 0.0;
 };
 
 namespace {
+
+// (a rendezvous has no error text of its own; the context's gtop_last_error belongs to the evaluation)
+inline void note_exception(void *, const char *) noexcept {}
+#define GTOP_CATCH_STATUS(x) GTOP_CATCH_WITH(note_exception, x, GTOP_ERR_INTERNAL)
+#define GTOP_CATCH_HUGE(x) GTOP_CATCH_WITH(note_exception, x, HUGE_VAL)
 
 // cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container sees the
 // whole host in hardware_concurrency())
@@ -100,16 +110,31 @@ void futex_wake_all(std::atomic<uint32_t> *w) {
   syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0);
 }
 
-// A caller gave up (timeout) or the owner aborted: nobody may block any more
+// A caller gave up (timeout) or the owner aborted: nobody may block any more.  The arrival bookkeeping is cleared
+// under the lock, so that the callers that return HUGE_VAL from here are no longer counted as waiting (a later
+// gtop_rendezvous_leave on their slots succeeds).  A leader that is evaluating right now finishes its launch on its
+// own; gtop_rendezvous_destroy waits for it.
 void break_rendezvous(gtop_rendezvous *r) {
-  r->broken.store(true, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->broken.store(true, std::memory_order_release);
+    for (auto &s : r->slots) s.waiting = false;
+    r->arrived = 0;
+  }
   r->generation.fetch_add(1, std::memory_order_release);
   futex_wake_all(&r->generation);
 }
 
-// Every active slot has arrived and the caller was elected under the lock: all the other callers are blocked
-// on the generation word, so nothing else touches the buffers.  Evaluate, publish, wake everybody.
+struct InsideGuard {   // counts the threads inside an entry point (gtop_rendezvous_destroy waits for zero)
+  gtop_rendezvous *r;
+  explicit InsideGuard(gtop_rendezvous *r_) : r(r_) { r->inside.fetch_add(1, std::memory_order_acq_rel); }
+  ~InsideGuard() { r->inside.fetch_sub(1, std::memory_order_acq_rel); }
+};
+
+// Every active slot has arrived and the caller was elected under the lock (which set r->evaluating): all the other
+// callers are blocked on the generation word, so nothing else touches the buffers.  Evaluate, publish, wake everybody.
 void run_generation(gtop_rendezvous *r) {
+  if (r->test_delay_s > 0.0) std::this_thread::sleep_for(std::chrono::duration<double>(r->test_delay_s));
   const auto t0 = std::chrono::steady_clock::now();
   const int st = gtop_eval_batch(r->ctx, r->n_slots, r->x.data(), r->cost.data(), r->grad.data());
   {
@@ -119,6 +144,7 @@ void run_generation(gtop_rendezvous *r) {
     r->launches++;
     for (auto &s : r->slots) s.waiting = false;
     r->arrived = 0;
+    r->evaluating = false;
   }
   r->generation.fetch_add(1, std::memory_order_release);
   futex_wake_all(&r->generation);
@@ -128,7 +154,7 @@ void run_generation(gtop_rendezvous *r) {
 
 extern "C" {
 
-int gtop_rendezvous_create(gtop_rendezvous **out, gtop_ctx *ctx, int n_slots, int m) {
+int gtop_rendezvous_create(gtop_rendezvous **out, gtop_ctx *ctx, int n_slots, int m) try {
   if (!out) return GTOP_ERR_INVALID;
   *out = nullptr;
   if (!ctx || n_slots < 1 || m < 2) return GTOP_ERR_INVALID;
@@ -140,6 +166,7 @@ int gtop_rendezvous_create(gtop_rendezvous **out, gtop_ctx *ctx, int n_slots, in
   // with a core per caller a short poll beats a sleep/wake pair (~50 us); with more callers than cores polling
   // only steals the cores the late arrivers need
   r->spin = n_slots <= usable_cores() ? 20000u : 0u;
+  if (const char *d = std::getenv("GTOP_RENDEZVOUS_TEST_DELAY_MS")) r->test_delay_s = std::atof(d) * 1e-3;
   r->slots.resize(n_slots);
   for (int i = 0; i < n_slots; ++i) r->slots[i] = gtop_rendezvous_slot{r, i, true, false, 0, HUGE_VAL};
   r->active = n_slots;
@@ -148,28 +175,43 @@ int gtop_rendezvous_create(gtop_rendezvous **out, gtop_ctx *ctx, int n_slots, in
   r->grad.assign((size_t)n_slots * r->n, 0.0);
   *out = r;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(nullptr)
 
-int gtop_rendezvous_destroy(gtop_rendezvous *r) {
+int gtop_rendezvous_destroy(gtop_rendezvous *r) try {
   if (!r) return GTOP_ERR_INVALID;
+  // Nobody may be left inside: callers asleep on the generation word are woken (the rendezvous is broken for good),
+  // and a leader that is inside gtop_eval_batch with this object's buffers is waited for — freeing them under its
+  // launch would be a use after free.
+  break_rendezvous(r);
+  for (;;) {
+    bool busy;
+    {
+      std::lock_guard<std::mutex> lk(r->mu);
+      busy = r->evaluating;
+    }
+    if (!busy && r->inside.load(std::memory_order_acquire) == 0) break;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
   delete r;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(nullptr)
 
 gtop_rendezvous_slot *gtop_rendezvous_get_slot(gtop_rendezvous *r, int i) {
   if (!r || i < 0 || i >= r->n_slots) return nullptr;
   return &r->slots[i];
 }
 
-double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *func_data) {
+double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *func_data) try {
   gtop_rendezvous_slot *s = static_cast<gtop_rendezvous_slot *>(func_data);
   if (!s || !s->owner || !x) return HUGE_VAL;
   gtop_rendezvous *r = s->owner;
+  InsideGuard inside(r);
   if (n != r->n || r->broken.load(std::memory_order_acquire)) return HUGE_VAL;
   bool leader;
   uint32_t gen;
   {
     std::lock_guard<std::mutex> lk(r->mu);
+    if (r->broken.load(std::memory_order_relaxed)) return HUGE_VAL;   // (broken between the test above and the lock)
     if (!s->active || s->waiting) return HUGE_VAL;   // left already / re-entered from a second thread
     // (the row is this caller's own; the previous generation's launch has completed, or it could not be here)
     std::memcpy(&r->x[(size_t)s->index * n], x, n * sizeof(double));
@@ -177,18 +219,32 @@ double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *f
     r->arrived++;
     gen = r->generation.load(std::memory_order_relaxed);
     leader = r->arrived == r->active;
+    if (leader) r->evaluating = true;
   }
   if (leader) {
     run_generation(r);   // the last arriver evaluates for everybody
   } else {
     for (unsigned i = 0; i < r->spin && r->generation.load(std::memory_order_acquire) == gen; ++i) __builtin_ia32_pause();
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
     while (r->generation.load(std::memory_order_acquire) == gen) {
       double left = 0.0;
       if (r->timeout_s > 0.0) {
         left = r->timeout_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (left <= 0.0) {   // a caller that never arrives (it exited without gtop_rendezvous_leave): give up, for everybody
-          break_rendezvous(r);
+        if (left <= 0.0) {
+          // The timeout is for a caller that never ARRIVES (it exited without gtop_rendezvous_leave).  Once everybody
+          // has arrived the wait is for the leader's launch — a module load on the first call, a large batch — which
+          // is not the callers' fault and ends by itself: the clock starts again.
+          bool launch_in_flight;
+          {
+            std::lock_guard<std::mutex> lk(r->mu);
+            launch_in_flight = r->evaluating;
+          }
+          if (launch_in_flight) {
+            t0 = std::chrono::steady_clock::now();
+            continue;
+          }
+          if (r->generation.load(std::memory_order_acquire) != gen) break;   // (published while we looked)
+          break_rendezvous(r);   // give up, for everybody
           break;
         }
       }
@@ -203,11 +259,12 @@ double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *f
   s->calls++;
   if (c < s->best) s->best = c;
   return c;
-}
+} GTOP_CATCH_HUGE(nullptr)
 
-int gtop_rendezvous_leave(gtop_rendezvous_slot *s) {
+int gtop_rendezvous_leave(gtop_rendezvous_slot *s) try {
   if (!s || !s->owner) return GTOP_ERR_INVALID;
   gtop_rendezvous *r = s->owner;
+  InsideGuard inside(r);
   bool leader;
   {
     std::lock_guard<std::mutex> lk(r->mu);
@@ -217,25 +274,26 @@ int gtop_rendezvous_leave(gtop_rendezvous_slot *s) {
     if (s->waiting) return GTOP_ERR_STATE;
     s->active = false;          // its row keeps its last x: evaluated along, never read
     r->active--;
-    leader = r->active > 0 && r->arrived == r->active;   // the others were only waiting for this one
+    leader = r->active > 0 && r->arrived == r->active && !r->broken.load(std::memory_order_relaxed);   // the others were only waiting for this one
+    if (leader) r->evaluating = true;
   }
   if (leader) run_generation(r);
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(nullptr)
 
-int gtop_rendezvous_set_timeout(gtop_rendezvous *r, double seconds) {
+int gtop_rendezvous_set_timeout(gtop_rendezvous *r, double seconds) try {
   if (!r || !(seconds >= 0.0)) return GTOP_ERR_INVALID;
   r->timeout_s = seconds;
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(nullptr)
 
-int gtop_rendezvous_abort(gtop_rendezvous *r) {
+int gtop_rendezvous_abort(gtop_rendezvous *r) try {
   if (!r) return GTOP_ERR_INVALID;
   break_rendezvous(r);
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(nullptr)
 
-int gtop_rendezvous_stats(gtop_rendezvous *r, int64_t *launches, double *launch_seconds, int64_t *callbacks) {
+int gtop_rendezvous_stats(gtop_rendezvous *r, int64_t *launches, double *launch_seconds, int64_t *callbacks) try {
   if (!r) return GTOP_ERR_INVALID;
   std::lock_guard<std::mutex> lk(r->mu);
   if (launches) *launches = r->launches;
@@ -246,6 +304,6 @@ int gtop_rendezvous_stats(gtop_rendezvous *r, int64_t *launches, double *launch_
     *callbacks = t;
   }
   return GTOP_OK;
-}
+} GTOP_CATCH_STATUS(nullptr)
 
 }  // extern "C"

@@ -4,9 +4,11 @@
  * This is the drop-in boundary.  Each entry point names the
  * reference interface it replaces as file:line into the reference tree
  * (EpicOne1/grad_traj_optimization).  Plain pointers and sizes only; no C++
- * or torch types; no exceptions cross this boundary — every function returns
- * a gtop_status (0 = OK) except gtop_cost_nlopt, whose shape is fixed by
- * NLopt's `nlopt_func`.
+ * or torch types; no exceptions cross this boundary (every entry point that can
+ * allocate is a function-try-block, csrc/gtop_guard.h: whatever is thrown inside
+ * comes back as GTOP_ERR_INTERNAL) — every function returns a gtop_status
+ * (0 = OK) except gtop_cost_nlopt / gtop_cost_nlopt_shared, whose shape is fixed
+ * by NLopt's `nlopt_func` (they return HUGE_VAL).
  *
  * Conventions
  *   m        number of polynomial segments (= #waypoints - 1), m >= 2
@@ -42,7 +44,9 @@ typedef enum {
   GTOP_ERR_INVALID = 1,   /* bad argument (NULL, m < 2, size mismatch ...) */
   GTOP_ERR_HIP = 2,       /* a HIP runtime call failed; see gtop_last_error */
   GTOP_ERR_NO_DEVICE = 3, /* no gfx950 device visible */
-  GTOP_ERR_STATE = 4      /* call order: SDF / problem / params not set */
+  GTOP_ERR_STATE = 4,     /* call order: SDF / problem / params not set */
+  GTOP_ERR_INTERNAL = 5   /* a C++ exception (e.g. std::bad_alloc) was caught at this
+                             boundary; see gtop_last_error.  The object stays usable. */
 } gtop_status;
 
 typedef enum { GTOP_F64 = 0, GTOP_F32 = 1 } gtop_dtype;
@@ -182,9 +186,15 @@ double gtop_cost_nlopt(unsigned n, const double *x, double *grad, void *ctx);
  * gtop_eval_batch gives that row.  A caller MUST call gtop_rendezvous_leave
  * when its optimizer returns, or the others wait for it: for ever by default,
  * or — after gtop_rendezvous_set_timeout(r, seconds) — until one of them has
- * waited that long, which breaks the rendezvous for everybody (every call,
- * pending or later, returns HUGE_VAL).  gtop_rendezvous_abort does the same at
- * once, from any thread (an error path that cannot make every caller leave).
+ * waited that long FOR A CALLER THAT HAS NOT ARRIVED, which breaks the
+ * rendezvous for everybody (every call, pending or later, returns HUGE_VAL).
+ * Time spent waiting for the elected caller's launch (everybody has arrived:
+ * a module load on the first call, a large batch) never counts against the
+ * timeout.  gtop_rendezvous_abort breaks it at once, from any thread (an
+ * error path that cannot make every caller leave).  After a break no slot
+ * counts as waiting: gtop_rendezvous_leave on it returns GTOP_OK.
+ * gtop_rendezvous_destroy breaks the rendezvous, waits until no thread is
+ * inside a call on it (a launch in flight uses its buffers) and frees it.
  * gtop_rendezvous_leave on a slot whose caller is inside the call right now
  * (i.e. from another thread) is refused with GTOP_ERR_STATE.  Returns
  * HUGE_VAL on misuse (wrong n, a slot that has left) or when the evaluation
@@ -242,8 +252,13 @@ int gtop_group_create(gtop_group **out, const int *devices, int n_devices);
 int gtop_group_destroy(gtop_group *g);
 int gtop_group_size(const gtop_group *g);
 gtop_ctx *gtop_group_context(gtop_group *g, int member);
+/* Text of the group's last error; with g == NULL, the text of the calling
+ * thread's last failed gtop_group_create (which member, and why). */
 const char *gtop_group_last_error(const gtop_group *g);
 const char *gtop_group_gather_backend(const gtop_group *g);
+/* The backend and the reason for it in words, e.g. "copy: peer copies, because
+ * librccl.so not found: ..." — a fallback from RCCL to copies is never silent. */
+const char *gtop_group_gather_note(const gtop_group *g);
 int gtop_group_set_params(gtop_group *g, const gtop_params *p);
 int gtop_group_init_sdf_map(gtop_group *g, const double map_size[3], const double origin[3], double resolution);
 int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts);
@@ -396,13 +411,20 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
 
 /* ---- tuning knobs (not in the reference) ---------------------------- */
 
-/* Launch geometry of the evaluation kernel.  A workgroup is always one
- * wavefront holding whole trajectories (waves: 0 or 1); samples per lane: 3
- * (ten lanes per polynomial segment: one trajectory of up to 6 segments per
- * wavefront), 6 (five lanes per segment: one trajectory of up to 12 segments
- * at a time, or two of up to 6), 0 = choose from B, m and dtype.  Other values,
- * and 3 with more than 6 segments, are GTOP_ERR_INVALID (at the call, resp. at
- * the evaluation).  Results do not depend on it beyond fp summation order. */
+/* Launch geometry of the evaluation kernel (csrc/gtop_kernels.hip,
+ * gtop_eval_plan).  A wavefront always holds whole segments; `waves` must be 0
+ * or 1 (the number of wavefronts per workgroup follows from the rule below and
+ * is not a knob).  samples_per_lane:
+ *   3   ten lanes per polynomial segment.  Up to 6 segments: one trajectory per
+ *       wavefront.  7 .. 12 segments: one trajectory over TWO wavefronts (a
+ *       128-thread workgroup, wavefront w holds segments 6w .. 6w+5).  More
+ *       than 12 segments (and the batched optimizer past 6): GTOP_ERR_INVALID
+ *       at the evaluation.
+ *   6   five lanes per segment: two trajectories of up to 6 segments per
+ *       wavefront, one of up to 12, or 12 segments at a time beyond that.
+ *   0   choose from B, m and dtype (measured rule).
+ * Other values are GTOP_ERR_INVALID at the call.  Results do not depend on the
+ * geometry beyond fp summation order. */
 int gtop_set_launch_geometry(gtop_ctx *ctx, int waves, int samples_per_lane);
 /* Batched optimizer: 2 (default) = one launch runs the whole loop (evaluate,
  * MMA update, evaluate, ... max_evals times) for every trajectory — they are

@@ -68,14 +68,15 @@ def write_scene(path, map_size, origin, resolution, obstacles, waypoints, veloci
     return path
 
 
-def run_scene(scene_file, max_evals, on_device=0, timeout=180):
-    """Runs the scene through the C++ shim (grad_traj_optimization_amd/gtop_scene_runner) and returns its JSON."""
+def run_scene(scene_file, max_evals, on_device=0, timeout=180, exe_name="gtop_scene_runner"):
+    """Runs the scene through the C++ shim (grad_traj_optimization_amd/gtop_scene_runner; exe_name =
+    "gtop_eigen_adapter": the same calls through the Eigen-signature adapter class) and returns its JSON."""
     import json
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "grad_traj_optimization_amd", "gtop_scene_runner")
-    assert os.path.exists(exe), "build() did not produce gtop_scene_runner"
+    exe = os.path.join(root, "grad_traj_optimization_amd", exe_name)
+    assert os.path.exists(exe), f"build() did not produce {exe_name}"
     out = subprocess.run([exe, str(scene_file), str(max_evals), str(on_device)], capture_output=True, text=True,
                          timeout=timeout)
     assert out.returncode == 0, out.stderr

@@ -61,7 +61,7 @@ def test_product_does_not_touch_the_oracle():
     assert "oracle" not in out
 
 
-def test_no_kernel_spills_to_scratch_memory():
+def test_no_kernel_spills_to_scratch_memory(tmp_path):
     """Build-time check (hipcc -Rpass-analysis=kernel-resource-usage, tools/kernel_resources.py): no instantiation of
     the evaluation kernel uses scratch memory.  The latency variant issues its distance-field loads through inline asm
     whose outstanding results the compiler cannot see; that is only sound while the register allocator keeps them
@@ -70,9 +70,43 @@ def test_no_kernel_spills_to_scratch_memory():
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
     kr = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kr)
-    rows, _ = kr.analyse(asm_out=os.path.join(ROOT, "grad_traj_optimization_amd", "csrc", "_obj", "resources.s"))
+    asm = str(tmp_path / "gtop_kernels.s")       # a 5 MB ISA dump: scratch, never in the source tree
+    rows, _ = kr.analyse(asm_out=asm)
     assert len(rows) >= 60
     bad = [r for r in rows if r["scratch"] or r["vgpr_spill"]]
     assert not bad, bad
     hot = [r for r in rows if r["kernel"].startswith("gtop_eval_wave_kernel<double, false, 3, 1, true, 2, GtopNoMma, false, false, 1>")]
     assert len(hot) == 1 and hot[0]["sgpr_spill"] == 0 and hot[0]["waves_per_simd"] == 2, hot
+    # the same dump, instruction by instruction: nothing names a hand-issued load's destination registers between its
+    # issue and the s_waitcnt that covers it (spill-free is necessary for that, not sufficient: a v_mov would do)
+    seen, violations = kr.check_asm_loads(asm)
+    assert seen >= 12 and not violations, violations[:5]
+    # and the checker itself sees what it is there to see
+    fake = tmp_path / "fake.s"
+    fake.write_text("k:\n\t;;#ASMSTART\n\tglobal_load_dwordx4 v[4:7], v1, s[2:3]\n\t;;#ASMEND\n"
+                    "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[8:11], v1, s[2:3]\n\t;;#ASMEND\n"
+                    "\ts_waitcnt vmcnt(1)\n\tv_add_f64 v[20:21], v[4:5], v[6:7]\n\tv_mov_b32_e32 v30, v9\n"
+                    "\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v31, v10\n\ts_endpgm\n")
+    seen, violations = kr.check_asm_loads(str(fake))
+    assert seen == 2 and len(violations) == 1 and "v_mov_b32_e32 v30, v9" in violations[0], violations
+
+
+def test_eigen_adapter_header_says_what_it_needs(tmp_path):
+    """include/grad_traj_optimization/grad_traj_optimizer.h (the reference-shaped class with Eigen signatures) must fail
+    with a readable message in an image without Eigen, and compile against the test double of the Eigen types
+    (tests/cpp/eigen_double) — build() makes gtop_eigen_adapter from it."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "grad_traj_optimization/grad_traj_optimizer.h"\nint main() { return 0; }\n')
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "grad_traj_optimization_amd", "csrc")]
+    bare = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", *inc, str(src)], capture_output=True, text=True)
+    if bare.returncode == 0:
+        pytest.skip("this image has Eigen")
+    assert "needs Eigen3" in bare.stderr
+    ok = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(ROOT, "tests", "cpp", "eigen_double"),
+                         *inc, str(src)], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    assert os.path.exists(os.path.join(ROOT, "grad_traj_optimization_amd", "gtop_eigen_adapter"))

@@ -76,3 +76,16 @@ def test_device_optimizer_option_follows_the_host_loop(run, scene_file):
     assert np.max(np.abs(np.array(dev["x1"]) - np.array(run["x1"]))) <= 1e-6 * max(1.0, np.max(np.abs(run["x1"])))
     assert len(dev["cost_curve"]) == 1          # the scene's own costFunc call after the optimisation, nothing per evaluation
     assert np.array_equal(np.array(dev["x0"]), np.array(run["x0"]))
+
+
+def test_eigen_signature_adapter_delegates(run, scene_file):
+    """include/grad_traj_optimization/grad_traj_optimizer.h: the global `GradTrajOptimizer` with the reference's Eigen
+    signatures (grad_traj_optimizer.h:20-39), driven as src/opti_node.cpp:58-106 drives the reference's class.  It is a
+    thin adapter over the shim, so the same scene must give the same bits as gtop_scene_runner.  (Compiled against
+    tests/cpp/eigen_double — the image has no Eigen: a check of the adapter's syntax and delegation only.)"""
+    ad = scenes.run_scene(scene_file, 40, exe_name="gtop_eigen_adapter")
+    assert ad["evals"] == run["evals"] == 40
+    assert np.array_equal(np.array(ad["segment_time"]), np.array(run["segment_time"]))
+    assert np.array_equal(np.array(ad["coeff1"]), np.array(run["coeff1"]))
+    n = run["evals"]
+    assert np.array_equal(np.array(ad["cost_curve"])[:n], np.array(run["cost_curve"])[1:n + 1])   # (the runner's own costFunc call comes first there)

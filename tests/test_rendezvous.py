@@ -112,3 +112,76 @@ def test_misuse_does_not_strand_the_callers(gtop):
             assert min(out.values()) >= 0.25
         with pytest.raises(gtop.GtopError):
             rdv.cost(2, b.x[2])                          # broken for everybody, late arrivals included
+
+
+def test_leave_after_a_break_and_timeout_against_a_slow_launch(gtop, monkeypatch):
+    """Round 4 (advisor): (1) a waiter's timeout must not fire while the elected caller is inside the launch — only a
+    caller that never ARRIVES breaks the rendezvous; (2) after a break the callers that came back with an error are no
+    longer counted as waiting, so leave() on their slots succeeds; (3) destroy waits for a launch in flight instead
+    of freeing the buffers under it.  GTOP_RENDEZVOUS_TEST_DELAY_MS makes the leader sleep before its launch."""
+    import time
+    mp = problem.make_map((40, 40, 20), density=0.03, seed=51)
+    b = problem.make_trajectories(3, 5, mp, seed=53)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    ctx.set_problem(b.T, b.Df)
+    c_ref, g_ref = ctx.eval_batch(b.x)
+
+    # (2) break by timeout (caller 2 never shows up), then leave on every slot
+    rdv = gtop.Rendezvous(ctx, 3, 5)
+    rdv.set_timeout(0.2)
+    out = {}
+
+    def waiter(i, rdv, out):
+        try:
+            out[i] = rdv.cost(i, b.x[i])
+        except gtop.GtopError:
+            out[i] = "broken"
+
+    th = [threading.Thread(target=waiter, args=(i, rdv, out), daemon=True) for i in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=30)
+        assert not t.is_alive()
+    assert out == {0: "broken", 1: "broken"}
+    assert [rdv.leave(i) for i in range(3)] == [0, 0, 0]      # (round 3: GTOP_ERR_STATE for ever on slots 0 and 1)
+    rdv.close()
+
+    # (1) everybody arrives, the launch takes 0.6 s, the timeout is 0.15 s: no break, everybody gets its row
+    monkeypatch.setenv("GTOP_RENDEZVOUS_TEST_DELAY_MS", "600")
+    rdv = gtop.Rendezvous(ctx, 3, 5)
+    rdv.set_timeout(0.15)
+    out = {}
+    th = [threading.Thread(target=waiter, args=(i, rdv, out), daemon=True) for i in range(3)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=30)
+        assert not t.is_alive()
+    assert time.perf_counter() - t0 >= 0.55
+    for i in range(3):
+        assert out[i] != "broken", out
+        assert out[i][0] == c_ref[i] and np.array_equal(out[i][1], g_ref[i])
+    assert [rdv.leave(i) for i in range(3)] == [0, 0, 0]
+    rdv.close()
+
+    # (3) abort while the leader is inside its (slow) launch, destroy at once: destroy waits for the launch
+    rdv = gtop.Rendezvous(ctx, 3, 5)
+    out = {}
+    th = [threading.Thread(target=waiter, args=(i, rdv, out), daemon=True) for i in range(3)]
+    for t in th:
+        t.start()
+    time.sleep(0.1)                       # all three have arrived; the leader sleeps in front of its launch
+    rdv.abort()
+    t0 = time.perf_counter()
+    rdv.close()                           # gtop_rendezvous_destroy
+    waited = time.perf_counter() - t0
+    for t in th:
+        t.join(timeout=30)
+        assert not t.is_alive()
+    assert waited >= 0.3, waited          # it did not free the buffers under the launch
+    assert all(v == "broken" for v in out.values()), out
+    ctx.close()
