@@ -263,7 +263,15 @@ def main():
     T = torch.tensor(batch.T[lo:hi], dtype=tdtype, device=dev)
     n = x.shape[1]
 
-    G = max(1, min(args.bucket, args.steps))
+    # Steps per graph.  Single GPU, no collective (the driver's N = 1 run): ALL steps of the timed region in one
+    # hipGraph — no gaps between graphs inside the region (round 3: forty 50-kernel graphs put 3-5 % of launch gaps
+    # into a 2 000-step region).  With a collective: buckets of --bucket steps, one all-gather each, and at least two
+    # buckets whenever there are two steps, so that a gather always has kernels to hide behind.
+    MAX_GRAPH_STEPS = 4096
+    if not collective:
+        G = max(1, min(args.steps, MAX_GRAPH_STEPS))
+    else:
+        G = max(1, min(args.bucket, args.steps // 2 if args.steps >= 2 else 1))
     while args.steps % G:
         G -= 1
     nbuckets = args.steps // G
@@ -281,26 +289,35 @@ def main():
             print(f"bench.py: PARITY FAILED {parity}", file=sys.stderr)
             sys.exit(3)
 
-    # ---- launch plan: one hipGraph per result ring buffer, G steps each ----
+    # ---- launch plan: one hipGraph per result ring buffer, G steps each, a device-clock stamp at either end ----
     from grad_traj_optimization_amd.distributed import ResultGatherPipeline
     stream = torch.cuda.current_stream(dev)
     graphs = None
+    STAMP_INIT = torch.tensor([2 ** 63 - 1, 0], dtype=torch.int64, device=dev)
+    stamps = STAMP_INIT.clone()          # [earliest, latest] device-clock stamp since the last reset
+    clock_hz = ctx.clock_hz()
 
-    def run_bucket_eager(j, steps=None):
+    def run_bucket_eager(j, steps=None, stamp=True):
+        if stamp:
+            ctx.clock_stamp(stamps)
         for s in range(G if steps is None else steps):
             ctx.eval_device(x, Df, T, pipe.cost_ring[j][s], pipe.grad_ring[j])
+        if stamp:
+            ctx.clock_stamp(stamps)     # behind the last kernel, in front of the bucket's all-gather
 
     def run_bucket_graph(j):
-        graphs[j].replay()
+        graphs[j % len(graphs)].replay()   # (a single-bucket run has one graph: every replay writes ring 0)
 
     pipe = ResultGatherPipeline(world, rank, G, hi - lo, tdtype, dev, run_bucket_eager,
                                 n_free=n, gather_grads=args.gather_grads, collective=collective)
     launch_mode = "eager"
     gather_mode = "none" if not collective else "host call per bucket, overlapped with the next bucket"
+    nrings = 2 if collective else min(2, nbuckets)
+    kernel_graphs = None                 # the same buckets without their all-gather (collective runs: what the gather costs)
     if not args.no_graph:
         def capture(with_gather):
             gs = []
-            for j in range(2):
+            for j in range(nrings):
                 gph = torch.cuda.CUDAGraph()
                 # thread_local: a HIP call from another thread (RCCL's watchdog) must not break the capture
                 with torch.cuda.graph(gph, capture_error_mode="thread_local"):
@@ -317,8 +334,8 @@ def main():
         for with_gather in attempts:
             try:
                 if with_gather:     # the communicator must exist (and have run once) before it is captured
-                    pipe.gather_now(0)
-                    pipe.gather_now(1)
+                    for j in range(nrings):
+                        pipe.gather_now(j)
                     torch.cuda.synchronize()
                 graphs = capture(with_gather)
                 pipe.run_bucket_fn = run_bucket_graph
@@ -326,6 +343,9 @@ def main():
                 launch_mode = "hipgraph"
                 if with_gather:
                     gather_mode = "captured in each bucket's hipGraph"
+                    kernel_graphs = capture(False)
+                else:
+                    kernel_graphs = graphs
                 break
             except Exception as e:   # capture unsupported: fall back, say so
                 print(f"bench.py: graph capture {'with the all-gather ' if with_gather else ''}failed ({e})", file=sys.stderr)
@@ -334,7 +354,7 @@ def main():
         if graphs is None:
             print("bench.py: using eager launches", file=sys.stderr)
     if rank == 0:
-        log(f"launch mode {launch_mode}, {G} steps per bucket, backend {backend if collective else 'none'}")
+        log(f"launch mode {launch_mode}, {G} steps per bucket x {nbuckets}, backend {backend if collective else 'none'}")
     run_bucket, drain = pipe.run_bucket, pipe.drain
 
     def barrier():
@@ -347,61 +367,95 @@ def main():
     #      lazily, hundreds of ms) is paid here too, not inside the timed region of a short run.
     upload_replays = 0
     if graphs is not None or collective:
-        for j in range(2):
+        for j in range(nrings):
             run_bucket(j)
             upload_replays += 1
         drain()
+        if kernel_graphs is not None and kernel_graphs is not graphs:
+            for gph in kernel_graphs:
+                gph.replay()
         torch.cuda.synchronize()
 
     # ---- warmup: exactly W steps (whole buckets through the timed path, the rest as single launches) ----
     for b in range(args.warmup // G):
         run_bucket(b)
     drain()
-    run_bucket_eager(0, args.warmup % G)
+    run_bucket_eager(0, args.warmup % G, stamp=False)
     torch.cuda.synchronize()
 
-    # ---- timed region: exactly K = nbuckets*G steps ----
-    short = args.steps < 500     # one or two graph launches: every event record inside is ~5 % of the region
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start_at = None
-    if collective:
-        # Ranks leave a barrier tens of microseconds apart, and the region's collective charges the last one's lateness
-        # to everybody (a fifth of a 0.1 ms region).  So the ranks of this node agree — before the barrier — on an instant
-        # shortly after it (CLOCK_MONOTONIC is one clock for all processes of a node) and start there, together.
-        tt0 = torch.tensor([time.perf_counter() + 0.003], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.broadcast(tt0, 0)
-        start_at = float(tt0.item())
-    barrier()
-    torch.cuda.synchronize()
-    if start_at is not None and 0.0 < start_at - time.perf_counter() < 0.01:   # (another node's clock, a slow barrier: start now)
-        while time.perf_counter() < start_at:
-            pass
-    t0 = time.perf_counter()
-    if not short:
-        ev0.record(stream)
-    for b in range(nbuckets):
-        run_bucket(b)
-    if not short:
-        ev1.record(stream)
-    drain()                    # the stream now also waits for the last bucket's all-gather (no host wait yet)
-    while not stream.query():  # poll: a blocking wait sleeps on an interrupt, tens of us after the last kernel ends
-        pass
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()   # this rank's K steps and their collectives are done; the job's time is the MAX over ranks
-    barrier()
-    elapsed = t1 - t0
-    if short:
-        kern_ms_timed = elapsed * 1e3 / args.steps    # host clock: launch call and completion poll included
-        timed_src = f"host clock around the timed region ({args.steps} launches in {nbuckets} graph launch(es))"
+    # ---- clock warm-up: CLOCK_WARMUP_MS of the timed region's own bucket replays, declared in `config`.  After the
+    #      parity gate's seconds of host work the card needs 10-20 ms of load to reach its sustained clocks
+    #      (tools/clock_ramp.py: 4.07 us per launch in the first 8 ms, 3.85 from 24 ms on, flat to 185 ms).  Round 3
+    #      warmed up only the probe behind the region, so `value` and `roofline.frac` described two clock states; now
+    #      the region, the device-clock stamps around it and the probe all run at the sustained clocks.  With a
+    #      collective every rank must replay the same number of buckets, so the count comes from the arguments alone.
+    CLOCK_WARMUP_MS = 40.0
+    clock_warmup_buckets = 0
+    if not collective:
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < CLOCK_WARMUP_MS * 1e-3:
+            for _ in range(max(1, 200 // G)):
+                run_bucket(clock_warmup_buckets)
+                clock_warmup_buckets += 1
+            torch.cuda.synchronize()
     else:
-        kern_ms_timed = ev0.elapsed_time(ev1) / args.steps     # avg per launch on the launch stream (HIP events)
-        timed_src = f"HIP events around the timed region ({args.steps} launches)"
-    # The roofline is about the KERNEL.  A short timed region (the driver's --steps 20) is one or two graph launches
-    # whose clock also sees the host's launch call (~10-25 us), so the kernel's sustained launch time is measured by a
-    # probe: 1 000 launches of the same kernel, graph-replayed 50 at a time, HIP events on the same stream, right
-    # after the timed region (no collective).  All three figures — timed region, probe, and the rocprofv3 average of
-    # the same command committed under profiles/ — go into the line side by side; `frac` is computed from the probe
-    # and `frac_source` says so.  `value` is never affected.
+        est_bucket_s = G * 5e-6 * max(1.0, Bl * m / (1024.0 * 6))
+        for _ in range(max(2, int(math.ceil(CLOCK_WARMUP_MS * 1e-3 / est_bucket_s)))):
+            run_bucket(clock_warmup_buckets)
+            clock_warmup_buckets += 1
+        drain()
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly K = nbuckets*G steps ----
+    def timed_region(run_b):
+        """K steps through run_b(bucket), bracketed by barrier + synchronize on both sides.  Returns this rank's host
+        seconds and the device clock's seconds between the region's first and last stamp (first kernel's dispatch to the
+        end of the last kernel, collectives of the buckets in between included)."""
+        stamps.copy_(STAMP_INIT)
+        start_at = None
+        if collective:
+            # Ranks leave a barrier tens of microseconds apart, and the region's collective charges the last one's
+            # lateness to everybody (a fifth of a 0.1 ms region).  So the ranks of this node agree — before the barrier
+            # — on an instant shortly after it (CLOCK_MONOTONIC is one clock for all processes of a node) and start
+            # there, together.
+            tt0 = torch.tensor([time.perf_counter() + 0.003], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.broadcast(tt0, 0)
+            start_at = float(tt0.item())
+        barrier()
+        torch.cuda.synchronize()
+        if start_at is not None and 0.0 < start_at - time.perf_counter() < 0.01:   # (another node's clock, a slow barrier: start now)
+            while time.perf_counter() < start_at:
+                pass
+        t0 = time.perf_counter()
+        for b in range(nbuckets):
+            run_b(b)
+        drain()                    # the stream now also waits for the last bucket's all-gather (no host wait yet)
+        while not stream.query():  # poll: a blocking wait sleeps on an interrupt, tens of us after the last kernel ends
+            pass
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()   # this rank's K steps and their collectives are done; the job's time is the MAX over ranks
+        barrier()
+        st = stamps.tolist()
+        return t1 - t0, (st[1] - st[0]) / clock_hz
+
+    elapsed, gpu_elapsed = timed_region(run_bucket)
+    kern_ms_host = elapsed * 1e3 / args.steps
+    kern_ms_gpu = gpu_elapsed * 1e3 / args.steps
+    timed_src = (f"device wall clock ({clock_hz / 1e6:.0f} MHz) stamped by a one-lane kernel in front of the first and behind "
+                 f"the last of the region's {args.steps} launches ({nbuckets} graph launch(es) of {G})")
+    host_src = f"host clock around the timed region (launch call(s) and completion poll included)"
+
+    # what the collective costs: the same K steps through the same buckets WITHOUT their all-gather, timed the same way
+    kernels_only = None
+    if collective and kernel_graphs is not None:
+        def run_kernels_only(b):
+            kernel_graphs[b % len(kernel_graphs)].replay()
+        kernels_only = timed_region(run_kernels_only)
+
+    # Cross-check of the kernel's launch time: a probe of 1 000 launches of the same kernel, graph-replayed 50 at a
+    # time, HIP events on the same stream, right after the timed region (no collective).  The roofline's `frac` is
+    # computed from the timed region's device-clock figure; the probe, the host clock's figure and the rocprofv3
+    # average of the same command committed under profiles/ go into the line beside it.
     GR, reps = 50, 20
     scratch = torch.zeros(GR, hi - lo, dtype=tdtype, device=dev)
 
@@ -420,10 +474,8 @@ def main():
             probe_mode = "hipgraph"
         except Exception:
             torch.cuda.synchronize()
-    # warm-up: 40 ms of the same replays.  After the parity gate's seconds of host work the card needs 10-20 ms of load
-    # to reach its sustained clocks (tools/clock_ramp.py: 4.07 us per launch in the first 8 ms, 3.85 from 24 ms on)
     t_w = time.perf_counter()
-    while time.perf_counter() - t_w < 0.040:
+    while time.perf_counter() - t_w < 0.010:      # (the clocks are up already; this covers the probe graph's upload)
         for r in range(reps):
             probe()
         torch.cuda.synchronize()
@@ -438,10 +490,17 @@ def main():
     probe_src = (f"HIP events around {reps * GR} launches of the same kernel ({probe_mode}, {GR} per graph) right after "
                  f"the timed region")
 
+    by_rank = None
     if collective:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        cdev = dev if backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed, gpu_elapsed] + (list(kernels_only) if kernels_only else [0.0, 0.0]),
+                            dtype=torch.float64, device=cdev)
+        allr = torch.zeros(world * 4, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 4).cpu()
+        by_rank = {"host_s": allr[:, 0].tolist(), "gpu_s": allr[:, 1].tolist(),
+                   "kernels_only_host_s": allr[:, 2].tolist(), "kernels_only_gpu_s": allr[:, 3].tolist()}
+        elapsed = float(allr[:, 0].max())          # the job's time: the slowest rank's
         # every rank must now hold every rank's costs (and gradients) of the last bucket
         last = pipe.all_costs(nbuckets - 1)
         assert torch.equal(last[rank], pipe.cost_ring[(nbuckets - 1) & 1])
@@ -462,7 +521,7 @@ def main():
 
         def gbs(ms):
             return launch_bytes / (ms * 1e-3) / 1e9 if ms else None
-        achieved = gbs(probe_ms)                               # GB/s, per launch on this rank
+        achieved = gbs(kern_ms_gpu)                            # GB/s per launch on this rank, from the timed region's device clock
         meas = measured_traffic(wkey)
         rocprof_us = meas.get("rocprof_avg_us")
         is_cfg1 = (Bl, m, args.grid, args.dtype) == (1024, 6, 200, "f64")
@@ -475,6 +534,8 @@ def main():
             "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # the same region on the device's own clock (rank 0): first launch's dispatch to the last kernel's end
+            "ms_per_step_gpu": kern_ms_gpu,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {
@@ -485,7 +546,11 @@ def main():
                 "sdf_grid": [args.grid] * 3, "sdf_occupied_frac": float(mp.occupancy.mean()),
                 "params": "opti_node.launch (ws=1, wc=5, alpha=10, d0=0.8, r=0.5), step=2",
                 "parallelism": par,
-                "launch": launch_mode, "steps_per_bucket": G, "graph_upload_replays": upload_replays,
+                # "single": no process group, no collective, all steps in one graph — what `--gpus 1` runs whether
+                # started directly or under torchrun; "collective": the bucketed path of N > 1
+                "path": "collective" if collective else "single",
+                "launch": launch_mode, "steps_per_bucket": G, "buckets": nbuckets, "graph_upload_replays": upload_replays,
+                "clock_warmup_ms": CLOCK_WARMUP_MS, "clock_warmup_steps": clock_warmup_buckets * G,
                 "gather": gather_mode,
                 "collective_bytes_per_bucket": (world * G * (hi - lo) * elem
                                                 + (world * (hi - lo) * n * elem if args.gather_grads else 0))
@@ -495,26 +560,49 @@ def main():
                 "bound": "hbm", "kernel": dominant_kernel(args.segments, hi - lo, args.dtype, bool(args.waves or args.spl)),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "frac_source": "probe",
+                "frac_source": "timed_region_gpu",
                 "traffic": meas.get("traffic_bytes"),
                 "traffic_source": meas.get("source"),
                 "algorithmic_bytes_per_eval": bpe, "evals_per_launch": hi - lo,
-                # the three launch times, side by side (us) and the fraction each gives
-                "avg_launch_us": probe_ms * 1e3,
-                "launch_us": {"probe": probe_ms * 1e3, "timed_region": kern_ms_timed * 1e3, "rocprof": rocprof_us},
-                "frac_by_source": {"probe": gbs(probe_ms) / HBM_PEAK_GBS,
-                                   "timed_region": gbs(kern_ms_timed) / HBM_PEAK_GBS,
+                # the launch time by every clock that saw it (us), and the fraction each gives.  timed_region_gpu and
+                # probe measure the same thing two ways and must agree; timed_region_host adds the host's launch call
+                # and completion poll (a fixed ~25 us per region: 30 % of the driver's 20-step region, 0.3 % of a
+                # 2 000-step one); rocprofv3's figure is its instrumented dispatch interval, which for a 4 us kernel
+                # is not the kernel (an EMPTY 1 024-workgroup kernel reads 4.4 us there: DESIGN.md 5.1).
+                "avg_launch_us": kern_ms_gpu * 1e3,
+                "launch_us": {"timed_region_gpu": kern_ms_gpu * 1e3, "probe": probe_ms * 1e3,
+                              "timed_region_host": kern_ms_host * 1e3, "rocprof": rocprof_us},
+                "frac_by_source": {"timed_region_gpu": gbs(kern_ms_gpu) / HBM_PEAK_GBS,
+                                   "probe": gbs(probe_ms) / HBM_PEAK_GBS,
+                                   "timed_region_host": gbs(kern_ms_host) / HBM_PEAK_GBS,
                                    "rocprof": (gbs(rocprof_us * 1e-3) / HBM_PEAK_GBS) if rocprof_us else None},
-                "launch_us_sources": {"probe": probe_src, "timed_region": timed_src,
+                "launch_us_sources": {"timed_region_gpu": timed_src, "probe": probe_src, "timed_region_host": host_src,
                                       "rocprof": meas.get("rocprof_source")},
-                "avg_launch_us_timed_region": kern_ms_timed * 1e3,
-                "launch_time_source": probe_src,
+                "gpu_vs_probe": kern_ms_gpu / probe_ms,
+                "launch_time_source": timed_src,
             },
             # what really bounds the kernel: instruction issue (the 200^3 field is cache resident)
-            "roofline_issue": issue_roofline(wkey, probe_ms * 1e3),
+            "roofline_issue": issue_roofline(wkey, kern_ms_gpu * 1e3),
             "parity": parity,
             "esdf_build_s": esdf_s,
         }
+        if collective:
+            # No scaling figure is computed here (the driver does that from the per-N lines); what the line adds is
+            # what the first real N > 1 run needs to be read: who the ranks were, how far apart they finished, and
+            # what the all-gather cost on top of the same buckets without it.
+            ko = max(by_rank["kernels_only_host_s"]) if kernels_only else None
+            out["collective"] = {
+                "backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+                "elapsed_s_by_rank": by_rank["host_s"], "elapsed_s_min": min(by_rank["host_s"]),
+                "elapsed_s_max": max(by_rank["host_s"]),
+                "gpu_elapsed_s_by_rank": by_rank["gpu_s"],
+                "kernels_only_elapsed_s_max": ko,
+                "kernels_only_gpu_elapsed_s_by_rank": by_rank["kernels_only_gpu_s"] if kernels_only else None,
+                "collective_exposed_us": (elapsed - ko) * 1e6 if ko else None,
+                "collective_exposed_us_how": "max-over-ranks host time of the timed region minus the same K steps through "
+                                             "the same buckets without their all-gather, timed the same way right after",
+            }
         if rehearsal:
             out["rehearsal"] = True
         if world == 1 and not args.no_extras:

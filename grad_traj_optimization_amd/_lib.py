@@ -122,6 +122,8 @@ def load_library():
         "gtop_get_cost_curve": (C.c_int, [vp, dp, dp, C.c_int, ip]),
         "gtop_clear_cost_curve": (C.c_int, [vp]),
         "gtop_set_launch_geometry": (C.c_int, [vp, C.c_int, C.c_int]),
+        "gtop_device_clock_stamp": (C.c_int, [vp, vp, vp]),
+        "gtop_device_clock_hz": (C.c_int, [vp, dp]),
         "gtop_rendezvous_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
         "gtop_rendezvous_destroy": (C.c_int, [vp]),
         "gtop_rendezvous_get_slot": (vp, [vp, C.c_int]),
@@ -324,6 +326,20 @@ class GtopContext:
                                            C.c_void_p(cost.data_ptr()), C.c_void_p(grad.data_ptr()),
                                            C.c_void_p(stream)))
         return cost, grad
+
+    def clock_stamp(self, minmax, stream=None):
+        """Enqueue a device-clock stamp: minmax (torch int64 tensor of 2 on the device, preset to [2**63 - 1, 0])
+        becomes [min(., t), max(., t)] of the device's wall clock (gtop_device_clock_stamp)."""
+        import torch
+        assert minmax.is_cuda and minmax.dtype == torch.int64 and minmax.numel() == 2 and minmax.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(minmax.device).cuda_stream
+        self._chk(self._L.gtop_device_clock_stamp(self._h, C.c_void_p(minmax.data_ptr()), C.c_void_p(stream)))
+
+    def clock_hz(self):
+        hz = C.c_double()
+        self._chk(self._L.gtop_device_clock_hz(self._h, C.byref(hz)))
+        return hz.value
 
     # -- setup / post-processing --
     TRAJ_STATS = ("time_sum", "length", "jerk", "mean_v", "max_v", "mean_a", "max_a", "acc_cost", "n_samples")

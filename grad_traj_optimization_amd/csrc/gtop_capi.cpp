@@ -1005,6 +1005,25 @@ int gtop_clear_cost_curve(gtop_ctx *c) try {
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)
 
+// ---- measurement aid: the device's own clock around enqueued work ----
+int gtop_device_clock_stamp(gtop_ctx *c, void *d_minmax, void *hip_stream) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!d_minmax) return fail(c, GTOP_ERR_INVALID, "device_clock_stamp: NULL buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, gtop_launch_clock_stamp(static_cast<unsigned long long *>(d_minmax), static_cast<hipStream_t>(hip_stream)));
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
+int gtop_device_clock_hz(gtop_ctx *c, double *hz) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!hz) return fail(c, GTOP_ERR_INVALID, "device_clock_hz: NULL");
+  int khz = 0;
+  HIPCHK(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+  if (khz <= 0) return fail(c, GTOP_ERR_HIP, "hipDeviceAttributeWallClockRate reports no wall clock");
+  *hz = 1e3 * (double)khz;
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
 int gtop_set_optimizer_fusion(gtop_ctx *c, int fused) try {
   if (!c) return GTOP_ERR_INVALID;
   if (fused < 0 || fused > 2) return fail(c, GTOP_ERR_INVALID, "optimizer fusion mode is 0, 1 or 2");

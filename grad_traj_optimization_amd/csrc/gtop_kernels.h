@@ -73,6 +73,8 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &p
 
 hipError_t gtop_launch_f64_to_f32(const double *src, float *dst, size_t nelem,
                                   hipStream_t stream);
+// minmax[0] = min(minmax[0], clock), minmax[1] = max(minmax[1], clock) of the device's constant-rate wall clock
+hipError_t gtop_launch_clock_stamp(unsigned long long *minmax, hipStream_t stream);
 
 // ---- ESDF construction (gtop_esdf.hip) -----------------------------------
 struct GtopGrid {

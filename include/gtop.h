@@ -443,6 +443,20 @@ int gtop_set_optimizer_fusion(gtop_ctx *ctx, int fused);
  * (fusion 1 or 2). */
 int gtop_set_optimizer_precision(gtop_ctx *ctx, int dtype);
 
+/* ---- measurement aid (not in the reference) --------------------------- */
+
+/* Enqueues a one-lane kernel on `hip_stream` that reads the device's constant-
+ * rate wall clock (the counter gtop_stop.maxtime is measured with) and folds it
+ * into d_minmax[0] = min(d_minmax[0], t), d_minmax[1] = max(d_minmax[1], t)
+ * (two uint64 in HBM; preset them to UINT64_MAX and 0).  Put one in front of and
+ * one behind a run of launches — e.g. as first and last node of a captured
+ * hipGraph — and (max - min) / gtop_device_clock_hz is the GPU's own time for
+ * them: no host clock and no profiler instrumentation inside the interval.
+ * bench.py times its region this way (`ms_per_step_gpu`). */
+int gtop_device_clock_stamp(gtop_ctx *ctx, void *d_minmax, void *hip_stream);
+/* Rate of that clock in Hz (hipDeviceAttributeWallClockRate; 100 MHz on MI355X). */
+int gtop_device_clock_hz(gtop_ctx *ctx, double *hz);
+
 #ifdef __cplusplus
 }
 #endif

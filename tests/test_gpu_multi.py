@@ -38,6 +38,12 @@ def test_bench_rank_path_with_rccl_at_world_size_one():
     assert r["config"]["collective_bytes_per_bucket"] == 10 * 1024 * 8 + 1024 * 45 * 8
     assert r["parity"]["ok"] and r["value"] > 1e4
     assert r["config"]["gather"] == "captured in each bucket's hipGraph"
+    assert r["config"]["path"] == "collective" and r["config"]["buckets"] == 4
+    col = r["collective"]
+    assert col["backend"] == "nccl" and col["ranks"] == col["rccl_ranks"] == 1
+    assert len(col["elapsed_s_by_rank"]) == 1 and col["elapsed_s_min"] == col["elapsed_s_max"] > 0
+    assert col["collective_exposed_us"] is not None and col["kernels_only_elapsed_s_max"] > 0
+    assert 0 < r["ms_per_step_gpu"] <= r["ms_per_step"] * 1.02      # the device's clock sees no more than the host's
 
 
 @pytest.mark.timeout(900)
@@ -50,6 +56,40 @@ def test_bench_rank_path_with_host_side_gathers():
 
 
 @pytest.mark.timeout(900)
+def test_bench_short_collective_run_still_has_two_buckets():
+    """The driver's N > 1 command is --steps 20: with one bucket its single all-gather would sit fully exposed behind
+    the last kernel; the bench splits such a run in (at least) two buckets."""
+    r = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"],
+               {"GTOP_BENCH_FORCE_DIST": "1"})
+    assert r["config"]["steps_per_bucket"] == 10 and r["config"]["buckets"] == 2 and r["steps"] == 20
+
+
+@pytest.mark.timeout(900)
+def test_gpus_1_is_the_single_path_however_it_is_started():
+    """`--gpus 1` must be byte for byte the path BENCH measures — no process group, no collective, every step in one
+    graph, the device-clock stamps — whether the driver starts bench.py directly or under torchrun."""
+    args = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"]
+    direct = _bench(args, {})
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", BENCH] + args,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    spawned = json.loads(lines[0])
+    for r in (direct, spawned):
+        assert r["config"]["path"] == "single" and "collective" not in r and "rehearsal" not in r
+        assert r["config"]["steps_per_bucket"] == 20 and r["config"]["buckets"] == 1 and r["config"]["gather"] == "none"
+        assert r["roofline"]["frac_source"] == "timed_region_gpu"
+        assert r["config"]["clock_warmup_ms"] == 40.0 and r["config"]["clock_warmup_steps"] >= 20
+        f = r["roofline"]["frac_by_source"]
+        assert abs(f["timed_region_gpu"] - f["probe"]) <= 0.08 * f["probe"], f      # two clocks, one kernel
+        assert abs(r["roofline"]["frac"] - f["timed_region_gpu"]) < 1e-12
+    assert direct["config"] == {**spawned["config"], "clock_warmup_steps": direct["config"]["clock_warmup_steps"]}
+
+
+@pytest.mark.timeout(900)
 def test_bench_self_launches_two_ranks_on_one_card():
     r = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--batch", "512", "--gather-grads"],
                {"GTOP_BENCH_BACKEND": "gloo", "GTOP_BENCH_SHARE_DEVICE": "1"})
@@ -57,6 +97,10 @@ def test_bench_self_launches_two_ranks_on_one_card():
     assert r["config"]["global_batch"] == 1024 and r["config"]["batch_per_gpu"] == 512
     assert r["parity"]["ok"] and r["value"] > 1e4
     assert "extras" not in r and "cpu_baseline" not in r   # N = 1 only
+    col = r["collective"]
+    assert col["backend"] == "gloo" and col["ranks"] == 2 and col["rccl_ranks"] == 0
+    assert len(col["elapsed_s_by_rank"]) == 2 and col["elapsed_s_max"] >= col["elapsed_s_min"] > 0
+    assert r["config"]["buckets"] == 2 and r["config"]["path"] == "collective"
 
 
 def test_two_contexts_on_one_device_equal_the_unsharded_batch(gtop):
