@@ -30,17 +30,25 @@ struct gtop_ctx {
 
   GtopGrid grid{};
   bool have_grid = false;
+  // The distance field.  sdf64 is the BOUNDARY copy, z fastest (src/sdf_map.cpp:172-173): what gtop_set_sdf uploads,
+  // the ESDF builder writes, gtop_get_sdf returns and the coarse voxel query reads; owned, or borrowed from
+  // gtop_set_sdf_device(GTOP_F64).  sdf32b is a borrowed fp32 field (gtop_set_sdf_device(GTOP_F32); no fp64 copy then).
+  // What the lookups of every kernel read are the CORNER RECORDS derived from it (gtop_records.hip),
+  // always owned: rec64 and rec32.  rec64 is rebuilt wherever the field changes.  The fp32 records of a rebuilt field:
+  // gtop_update_sdf_map (host points, synchronous) defers them to the first fp32 evaluation unless one has been seen
+  // on this context (`fp32_in_use`, sticky), because they are a third of the pass's writes;
+  // gtop_update_sdf_map_device (asynchronous, capturable into a hipGraph) always builds them behind the fp64 ones, so
+  // that a REPLAY of the captured rebuild — which never passes through this host code again — leaves both current.
   double *sdf64 = nullptr;
-  float *sdf32 = nullptr;
-  // The fp32 copy of a rebuilt field.  gtop_update_sdf_map (host points, synchronous) defers it to the first fp32
-  // evaluation unless one has been seen on this context (`fp32_in_use`, sticky), because the copy is a third of the
-  // build's writes; gtop_update_sdf_map_device (asynchronous, capturable into a hipGraph) always has the last sweep
-  // write it beside the fp64 field, so that a REPLAY of the captured rebuild — which never passes through this host
-  // code again — leaves both precisions current.
-  bool sdf32_stale = false;
+  const float *sdf32b = nullptr;
+  bool own64 = false;
+  size_t sdf_cap64 = 0;              // elements, for the owned buffer
+  double *rec64 = nullptr;
+  float *rec32 = nullptr;
+  size_t rec_cap64 = 0, rec_cap32 = 0;   // records
+  bool rec64_ok = false, rec32_ok = false;   // the records hold the current field
+  bool rec32_stale = false;          // ... or must be rebuilt from sdf64 before the next fp32 use
   bool fp32_in_use = false;
-  bool own64 = false, own32 = false;
-  size_t sdf_cap64 = 0, sdf_cap32 = 0;   // elements, for owned buffers
 
   // ESDF construction workspace
   uint8_t *occ = nullptr;
@@ -152,12 +160,30 @@ int fill_grid(gtop_ctx *c, int nx, int ny, int nz, const double origin[3], const
 
 void release_sdf(gtop_ctx *c) {
   if (c->own64 && c->sdf64) (void)hipFree(c->sdf64);
-  if (c->own32 && c->sdf32) (void)hipFree(c->sdf32);
   c->sdf64 = nullptr;
-  c->sdf32 = nullptr;
-  c->sdf32_stale = false;
-  c->own64 = c->own32 = false;
-  c->sdf_cap64 = c->sdf_cap32 = 0;
+  c->sdf32b = nullptr;
+  c->own64 = false;
+  c->sdf_cap64 = 0;
+  c->rec64_ok = c->rec32_ok = c->rec32_stale = false;   // (the record buffers stay: grow-only)
+}
+
+// room for the corner records of the current grid, both precisions (allocated up front: a captured map rebuild must
+// not allocate, and the first fp32 evaluation may come from inside a capture)
+int ensure_records(gtop_ctx *c) {
+  const size_t nrec = gtop_record_count(c->grid);
+  if (c->rec_cap64 < nrec) {
+    if (c->rec64) (void)hipFree(c->rec64);
+    c->rec64 = nullptr; c->rec_cap64 = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->rec64), nrec * 4 * sizeof(double)));
+    c->rec_cap64 = nrec;
+  }
+  if (c->rec_cap32 < nrec) {
+    if (c->rec32) (void)hipFree(c->rec32);
+    c->rec32 = nullptr; c->rec_cap32 = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->rec32), nrec * 4 * sizeof(float)));
+    c->rec_cap32 = nrec;
+  }
+  return GTOP_OK;
 }
 
 int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
@@ -167,12 +193,36 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->sdf64), nvox * sizeof(double)));
     c->own64 = true; c->sdf_cap64 = nvox;
   }
-  if (!c->own32 || c->sdf_cap32 < nvox) {
-    if (c->own32 && c->sdf32) (void)hipFree(c->sdf32);
-    c->sdf32 = nullptr; c->own32 = false; c->sdf_cap32 = 0;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->sdf32), nvox * sizeof(float)));
-    c->own32 = true; c->sdf_cap32 = nvox;
+  c->sdf32b = nullptr;
+  return ensure_records(c);
+}
+
+// Corner records of the fp64 field on stream `s` (the whole field, or the voxel box [vlo, vhi]); the fp32 records too
+// when they are wanted now, otherwise they are marked stale and the first fp32 use builds them.
+int build_records_on_stream(gtop_ctx *c, hipStream_t s, bool fp32_now, const int *vlo = nullptr, const int *vhi = nullptr) {
+  HIPCHK(c, (gtop_launch_build_records<double, double>(c->grid, c->sdf64, c->rec64, vlo, vhi, s)));
+  c->rec64_ok = true;
+  if (fp32_now) {
+    HIPCHK(c, (gtop_launch_build_records<double, float>(c->grid, c->sdf64, c->rec32, vlo, vhi, s)));
+    c->rec32_ok = true;
+    c->rec32_stale = false;
+  } else {
+    c->rec32_ok = false;
+    c->rec32_stale = true;
   }
+  return GTOP_OK;
+}
+
+// the fp32 records, current, before an fp32 use enqueued on stream `s`
+int fp32_records_ready(gtop_ctx *c, hipStream_t s) {
+  c->fp32_in_use = true;
+  if (c->rec32_ok) return GTOP_OK;
+  if (!c->rec32_stale || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
+  // only a synchronous entry point (gtop_set_sdf, gtop_init_sdf_map, gtop_update_sdf_map) leaves the records stale,
+  // and it has synchronised: the fp64 field is complete whatever stream `s` is
+  HIPCHK(c, (gtop_launch_build_records<double, float>(c->grid, c->sdf64, c->rec32, nullptr, nullptr, s)));
+  c->rec32_ok = true;
+  c->rec32_stale = false;
   return GTOP_OK;
 }
 
@@ -275,7 +325,7 @@ int gtop_destroy(gtop_ctx *c) try {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   release_sdf(c);
-  void *bufs[] = {c->occ, c->tmp1, c->tmp2, c->rows, c->boxes, c->d_q, c->d_pts,
+  void *bufs[] = {c->rec64, c->rec32, c->occ, c->tmp1, c->tmp2, c->rows, c->boxes, c->d_q, c->d_pts,
                   c->d_T, c->d_Df, c->d_x, c->d_cost, c->d_grad,
                   c->mma_vec, c->mma_scal, c->mma_int, c->mma_f, c->mma_g, c->mma_lb, c->mma_ub, c->mma_res};
   for (void *p : bufs)
@@ -311,8 +361,7 @@ int gtop_set_sdf(gtop_ctx *c, const double *dist_host, int nx, int ny, int nz,
   const size_t nvox = (size_t)nx * ny * nz;
   if ((rc = own_sdf_buffers(c, nvox))) { c->have_grid = false; return rc; }
   HIPCHK(c, hipMemcpyAsync(c->sdf64, dist_host, nvox * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, c->stream));
-  c->sdf32_stale = false;
+  if ((rc = build_records_on_stream(c, c->stream, c->fp32_in_use))) return rc;   // the upload transform
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)
@@ -326,10 +375,18 @@ int gtop_set_sdf_device(gtop_ctx *c, int dtype, const void *dist_dev, int nx, in
   int rc = fill_grid(c, nx, ny, nz, origin, map_size, resolution);
   if (rc) return rc;
   release_sdf(c);
-  if (dtype == GTOP_F64)
+  if ((rc = ensure_records(c))) { c->have_grid = false; return rc; }
+  // The buffer is borrowed as the boundary copy (gtop_get_sdf and the coarse voxel query read it in place); the
+  // corner records the lookups read are derived from it HERE — a caller that rewrites the buffer calls again.
+  if (dtype == GTOP_F64) {
     c->sdf64 = const_cast<double *>(static_cast<const double *>(dist_dev));
-  else
-    c->sdf32 = const_cast<float *>(static_cast<const float *>(dist_dev));
+    if ((rc = build_records_on_stream(c, c->stream, c->fp32_in_use))) return rc;
+  } else {
+    c->sdf32b = static_cast<const float *>(dist_dev);
+    HIPCHK(c, (gtop_launch_build_records<float, float>(c->grid, c->sdf32b, c->rec32, nullptr, nullptr, c->stream)));
+    c->rec32_ok = true;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)
 
@@ -347,8 +404,7 @@ int gtop_init_sdf_map(gtop_ctx *c, const double map_size[3], const double origin
   if ((rc = ensure(c, &c->occ, &c->cap_occ, nvox))) return rc;
   // sdf_map.cpp:22-23: distance 10000, occupancy 0
   HIPCHK(c, gtop_launch_esdf_reset(c->occ, c->sdf64, nvox, c->stream));
-  HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, nvox, c->stream));
-  c->sdf32_stale = false;
+  if ((rc = build_records_on_stream(c, c->stream, c->fp32_in_use))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)
@@ -369,12 +425,10 @@ static int update_sdf_map_on_stream(gtop_ctx *c, const double *d_pts, int npts, 
   // writes every voxel (10000 where the line holds no obstacle, as the reset would have left it)
   HIPCHK(c, gtop_launch_esdf_reset(c->occ, nullptr, nvox, s));
   HIPCHK(c, gtop_launch_esdf_mark(g, d_pts, npts, c->occ, s));         // setOccupancy
-  // the fp32 copy rides in the x sweep's stores (device-side: holds for graph replays too) when it is wanted now;
-  // otherwise the first fp32 evaluation converts (host-synchronous caller only, see gtop_ctx)
-  float *const copy32 = (c->sdf32 && (convert_now || c->fp32_in_use)) ? c->sdf32 : nullptr;
-  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, copy32, s));   // updateESDF3d
-  c->sdf32_stale = c->sdf32 && !copy32;
-  return GTOP_OK;
+  HIPCHK(c, gtop_launch_esdf_build(g, c->occ, c->tmp1, c->tmp2, c->rows, c->sdf64, nullptr, s));   // updateESDF3d
+  // the corner records behind it, on the same stream (device-side: holds for graph replays too); the fp32 ones now
+  // when they are wanted now, otherwise at the first fp32 evaluation (host-synchronous caller only, see gtop_ctx)
+  return build_records_on_stream(c, s, convert_now || c->fp32_in_use);
 }
 
 int gtop_update_sdf_map(gtop_ctx *c, const double *pts, int npts) try {
@@ -445,7 +499,7 @@ int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *g
   int rc = check_eval_state(c);
   if (rc) return rc;
   if (c->B == 0) return fail(c, GTOP_ERR_STATE, "gtop_set_problem has not been called");
-  if (!c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+  if (!c->rec64_ok) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
   if (B < 1 || B > c->B || !x || !cost || !grad)
     return fail(c, GTOP_ERR_INVALID, "eval_batch: 1 <= B <= problem batch, non-NULL buffers");
   HIPCHK(c, hipSetDevice(c->device));
@@ -479,7 +533,7 @@ int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *g
     volatile uint64_t *out = reinterpret_cast<volatile uint64_t *>(c->pin + bn);
     if (poll)
       for (size_t i = 0; i < nout; ++i) out[i] = c->poll_sentinel;
-    if ((rc = launch_eval<double>(c, c->sdf64, B, c->m, dpin, c->d_Df, c->d_T, c->t_stride, dpin + bn,
+    if ((rc = launch_eval<double>(c, c->rec64, B, c->m, dpin, c->d_Df, c->d_T, c->t_stride, dpin + bn,
                                   dpin + bn + B, c->stream)))
       return rc;
     bool done = false;
@@ -509,7 +563,7 @@ int gtop_eval_batch(gtop_ctx *c, int B, const double *x, double *cost, double *g
     return GTOP_OK;
   }
   HIPCHK(c, hipMemcpyAsync(c->d_x, x, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  if ((rc = launch_eval<double>(c, c->sdf64, B, c->m, c->d_x, c->d_Df, c->d_T, c->t_stride, c->d_cost,
+  if ((rc = launch_eval<double>(c, c->rec64, B, c->m, c->d_x, c->d_Df, c->d_T, c->t_stride, c->d_cost,
                                 c->d_grad, c->stream)))
     return rc;
   HIPCHK(c, hipMemcpyAsync(cost, c->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -558,19 +612,11 @@ int gtop_eval_device(gtop_ctx *c, int dtype, int B, int m, const void *d_x, cons
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   if (dtype == GTOP_F64) {
-    if (!c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
-    return launch_eval<double>(c, c->sdf64, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
+    if (!c->rec64_ok) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+    return launch_eval<double>(c, c->rec64, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
   } else if (dtype == GTOP_F32) {
-    if (!c->sdf32) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
-    c->fp32_in_use = true;
-    if (c->sdf32_stale) {
-      // only gtop_update_sdf_map leaves the copy stale, and it has synchronised: the fp64 field is complete whatever
-      // stream `s` is (gtop_update_sdf_map_device converts on its own stream, behind its build)
-      const GtopGrid &g = c->grid;
-      HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, (size_t)g.nx * g.ny * g.nz, s));
-      c->sdf32_stale = false;
-    }
-    return launch_eval<float>(c, c->sdf32, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
+    if ((rc = fp32_records_ready(c, s))) return rc;
+    return launch_eval<float>(c, c->rec32, B, m, d_x, d_Df, d_T, time_stride, d_cost, d_grad, s);
   }
   return fail(c, GTOP_ERR_INVALID, "bad dtype");
 } GTOP_CATCH_STATUS(c)
@@ -723,13 +769,13 @@ int gtop_set_moving_boxes(gtop_ctx *c, int nbox, const double *p0, const double 
 int gtop_edt_query_device(gtop_ctx *c, int N, const void *d_pos, const void *d_time, void *d_dist, void *d_grad,
                           void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
-  if (!c->have_grid || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+  if (!c->have_grid || !c->rec64_ok) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
   if (N < 0) return fail(c, GTOP_ERR_INVALID, "edt_query: N < 0");
   if (N == 0) return GTOP_OK;
   if (!d_pos || !d_time || !d_dist || !d_grad) return fail(c, GTOP_ERR_INVALID, "edt_query: NULL buffer");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n3 = (size_t)c->nbox * 3;
-  HIPCHK(c, gtop_launch_edt_query(c->grid, c->sdf64, c->nbox, c->boxes, c->boxes + n3, c->boxes + 2 * n3, N,
+  HIPCHK(c, gtop_launch_edt_query(c->grid, c->sdf64, c->rec64, c->nbox, c->boxes, c->boxes + n3, c->boxes + 2 * n3, N,
                                   static_cast<const double *>(d_pos), static_cast<const double *>(d_time),
                                   static_cast<double *>(d_dist), static_cast<double *>(d_grad),
                                   static_cast<hipStream_t>(hip_stream)));
@@ -764,7 +810,7 @@ int gtop_edt_coarse_query_device(gtop_ctx *c, int N, const void *d_pos, const vo
   if (!d_pos || !d_time || !d_dist) return fail(c, GTOP_ERR_INVALID, "edt_coarse_query: NULL buffer");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n3 = (size_t)c->nbox * 3;
-  HIPCHK(c, gtop_launch_edt_query(c->grid, c->sdf64, c->nbox, c->boxes, c->boxes + n3, c->boxes + 2 * n3, N,
+  HIPCHK(c, gtop_launch_edt_query(c->grid, c->sdf64, c->rec64, c->nbox, c->boxes, c->boxes + n3, c->boxes + 2 * n3, N,
                                   static_cast<const double *>(d_pos), static_cast<const double *>(d_time),
                                   static_cast<double *>(d_dist), nullptr, static_cast<hipStream_t>(hip_stream)));
   return GTOP_OK;
@@ -803,7 +849,7 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
     return fail(c, GTOP_ERR_INVALID, "optimize_device: need B >= 0, m >= 2, time_stride in {0, m}");
   if (B == 0) return GTOP_OK;
   if (!d_x || !d_Df || !d_T || !d_lb || !d_ub) return fail(c, GTOP_ERR_INVALID, "optimize_device: NULL buffer");
-  if (!c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
+  if (!c->rec64_ok) return fail(c, GTOP_ERR_STATE, "no fp64 distance field resident");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const size_t n = 9 * (size_t)(m - 1), bn = (size_t)B * n;
@@ -836,7 +882,7 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   st.max_evals = max_evals;
   GtopKernelArgs<double> a;
   fill_args(c, a);
-  a.sdf = c->sdf64;
+  a.sdf = c->rec64;
   a.x = st.xcur;
   a.Df = static_cast<const double *>(d_Df);
   a.T = static_cast<const double *>(d_T);
@@ -850,15 +896,9 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   GtopKernelArgs<float> a32;
   if (f32) {
     if (!fused) return fail(c, GTOP_ERR_INVALID, "optimize: fp32 evaluations need a fused launch form (gtop_set_optimizer_fusion 1 or 2)");
-    if (!c->sdf32) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
-    c->fp32_in_use = true;
-    if (c->sdf32_stale) {   // (only gtop_update_sdf_map leaves it stale, and it has synchronised: see gtop_eval_device)
-      const GtopGrid &g = c->grid;
-      HIPCHK(c, gtop_launch_f64_to_f32(c->sdf64, c->sdf32, (size_t)g.nx * g.ny * g.nz, s));
-      c->sdf32_stale = false;
-    }
+    if ((rc = fp32_records_ready(c, s))) return rc;
     fill_args(c, a32);
-    a32.sdf = c->sdf32;
+    a32.sdf = c->rec32;
     a32.x = nullptr;   // (the loop reads its trial point from LDS)
     a32.Df = reinterpret_cast<const float *>(d_Df);   // fp64 rows: staged by the kernel as such
     a32.T = reinterpret_cast<const float *>(d_T);
@@ -889,7 +929,7 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
       // one launch per iteration: the evaluation kernel runs the MMA update as its epilogue
       HIPCHK(c, launch_loop());
     } else {
-      if ((rc = launch_eval<double>(c, c->sdf64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s,
+      if ((rc = launch_eval<double>(c, c->rec64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s,
                                     /*for_optimizer=*/true)))   // the geometry the fused modes run: same bits
         return rc;
       HIPCHK(c, gtop_launch_mma_update(st, B, (int)n, c->mma_f, c->mma_g, s));

@@ -19,8 +19,8 @@
 // by every lane in step, so their reads are broadcasts.  The N x 3 query
 // positions and gradients cross HBM as whole rows of the workgroup (768
 // consecutive doubles, transposed through LDS at an odd stride), not as
-// stride-3 accesses.  fp64.  Gather-bound: 8 corner loads (the corner pairs along
-// z share a sector) + 64 B of query/result per lane; algorithmic bytes per query
+// stride-3 accesses.  fp64.  Gather-bound: the 8 corners are 64 contiguous bytes of
+// the corner records + 64 B of query/result per lane; algorithmic bytes per query
 // 8*8 + 4*8 + 4*8 = 128.
 // COARSE = EDTEnvironment::evaluateCoarseEDT (src/edt_environment.cpp:124-136):
 // the distance of the voxel holding the position (SDFMap::getDistance(pos),
@@ -38,7 +38,8 @@ constexpr int kBoxChunk = 128;   // boxes staged in LDS per pass
 
 template <bool COARSE>
 __global__ void __launch_bounds__(256)
-edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, const double *__restrict__ box_p0,
+edt_query_kernel(const GtopGrid g, const double *__restrict__ field, const double *__restrict__ rec, int nbox,
+                 const double *__restrict__ box_p0,
                  const double *__restrict__ box_vel, const double *__restrict__ box_scale, int N,
                  const double *__restrict__ pos, const double *__restrict__ time, double *__restrict__ dist,
                  double *__restrict__ grad) {
@@ -77,24 +78,18 @@ edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, c
       idx[k] = (int)floor((pm - g.origin[k]) * g.res_inv);
       diff[k] = (p[k] - ((idx[k] + 0.5) * g.res + g.origin[k])) * g.res_inv;
     }
-    // The 8 corner loads of sdf_map.cpp:211-219, each index clamped per axis (getDistance(int,int,int), :166-174), as
-    // FOUR 16-byte loads: z is the fastest axis, so the two z-corners of an (x,y) column are neighbours — the pair
-    // (D[zb], D[zb+1]) with zb = clamp(iz, 0, nz-2) holds both, and at a z border, where both corners clamp to the
-    // same voxel, that voxel is the pair's first (iz < 0) or second (iz > nz-2) element.  Same values, half the
-    // requests (the lookup of the cost/gradient kernel, gtop_kernels.hip corner_loads, does the same).
+    // The 8 corner loads of sdf_map.cpp:211-219, each index clamped per axis (getDistance(int,int,int), :166-174),
+    // from the CORNER RECORDS (gtop_records.hip): the two consecutive records of levels iz and iz + 1 hold all eight,
+    // clamps applied — 64 contiguous bytes, four 16-byte loads at one address (round 3 read four (z, z+1) pairs from
+    // four lines: 4.24 lines of 128 bytes per query, 16 bytes used of each; now 1.25).
     {
-      struct __attribute__((packed, aligned(8))) Pair { double lo, hi; };
-      const int zb = min(max(idx[2], 0), g.nz - 2);
-      const bool z_low = idx[2] < 0, z_high = idx[2] > g.nz - 2;
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          const int cx = min(max(idx[0] + x, 0), g.nx - 1), cy = min(max(idx[1] + y, 0), g.ny - 1);
-          const Pair pr = *reinterpret_cast<const Pair *>(field + ((size_t)cx * g.ny + cy) * g.nz + zb);
-          values[x][y][0] = z_high ? pr.hi : pr.lo;
-          values[x][y][1] = z_low ? pr.lo : pr.hi;
-        }
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const int cx = min(max(idx[0], -1), g.nx - 1) + 1, cy = min(max(idx[1], -1), g.ny - 1) + 1;
+      const int cz = min(max(idx[2], -1), g.nz - 1) + 1;
+      const d2 *r = reinterpret_cast<const d2 *>(rec + 4 * (((size_t)cx * (g.ny + 1) + cy) * (g.nz + 2) + cz));
+      const d2 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+      values[0][0][0] = q0.x; values[0][1][0] = q0.y; values[1][0][0] = q1.x; values[1][1][0] = q1.y;
+      values[0][0][1] = q2.x; values[0][1][1] = q2.y; values[1][0][1] = q3.x; values[1][1][1] = q3.y;
     }
   }
   // min over the boxes (edt_environment.cpp:26-73): at the 8 corner centres (:96-98), or at the position (:131)
@@ -199,15 +194,15 @@ edt_query_kernel(const GtopGrid g, const double *__restrict__ field, int nbox, c
 
 }  // namespace
 
-hipError_t gtop_launch_edt_query(const GtopGrid &g, const double *field, int nbox, const double *box_p0,
+hipError_t gtop_launch_edt_query(const GtopGrid &g, const double *field, const double *rec, int nbox, const double *box_p0,
                                  const double *box_vel, const double *box_scale, int N, const double *pos,
                                  const double *time, double *dist, double *grad, hipStream_t stream) {
   if (N <= 0) return hipSuccess;
   if (grad)
-    hipLaunchKernelGGL(edt_query_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, stream, g, field, nbox, box_p0,
+    hipLaunchKernelGGL(edt_query_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, stream, g, field, rec, nbox, box_p0,
                        box_vel, box_scale, N, pos, time, dist, grad);
   else   // evaluateCoarseEDT: no interpolation, no gradient
-    hipLaunchKernelGGL(edt_query_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, stream, g, field, nbox, box_p0,
+    hipLaunchKernelGGL(edt_query_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, stream, g, field, rec, nbox, box_p0,
                        box_vel, box_scale, N, pos, time, dist, grad);
   return hipGetLastError();
 }

@@ -19,7 +19,9 @@ struct GtopKernelArgs {
   R *cost;       // [B]
   R *grad;       // [B][n]
   int B, m, t_stride;
-  // shared distance field (HBM, z fastest) — SDFMap fields, sdf_map.h:13-23
+  // shared distance field — SDFMap fields, sdf_map.h:13-23.  `sdf` is the resident CORNER-RECORD copy
+  // (gtop_records.hip: record (ix+1, iy+1, level+1) = the four clamped (x,y) corners of base index (ix,iy) at one z
+  // level, records z-fastest), not the boundary's z-fastest buffer; nx, ny, nz are the voxel grid's.
   const R *sdf;
   int nx, ny, nz;
   R origin[3];
@@ -95,6 +97,14 @@ size_t gtop_esdf_rows_ints(const GtopGrid &g);   // ints of row workspace the bu
 hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,
                                   double *dist, float *dist32, hipStream_t stream);
 
+// ---- corner records (gtop_records.hip): the gather-friendly resident copy the lookups read ----
+size_t gtop_record_count(const GtopGrid &g);   // (nx+1)(ny+1)(nz+2) records of 4 values
+// S -> D in {double -> double, double -> float, float -> float}; vlo / vhi: inclusive voxel box whose records are
+// rebuilt (NULL = the whole field)
+template <typename S, typename D>
+hipError_t gtop_launch_build_records(const GtopGrid &g, const S *field, D *rec, const int *vlo, const int *vhi,
+                                     hipStream_t stream);
+
 // the optimizer loop: st.iters x {cost/gradient at st.xcur, CCSA-MMA update} per trajectory in one launch (fp64; a plan
 // made with for_optimizer = true); honours st.x0_init / st.out_*
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
@@ -119,7 +129,8 @@ hipError_t gtop_launch_eval_trajectories(int B, int m, const double *coeff, cons
                                          hipStream_t stream);
 
 // ---- static field + moving boxes (gtop_edt.hip) -----------------------------
-hipError_t gtop_launch_edt_query(const GtopGrid &g, const double *field, int nbox, const double *box_p0,
+// field: the z-fastest fp64 buffer (the coarse query's voxel values); rec: its corner records (the interpolating query)
+hipError_t gtop_launch_edt_query(const GtopGrid &g, const double *field, const double *rec, int nbox, const double *box_p0,
                                  const double *box_vel, const double *box_scale, int N, const double *pos,
                                  const double *time, double *dist, double *grad, hipStream_t stream);
 

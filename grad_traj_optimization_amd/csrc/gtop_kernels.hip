@@ -190,12 +190,6 @@ __device__ __forceinline__ double speed_sqrt(double s) {
   return g;
 }
 __device__ __forceinline__ float speed_sqrt(float s) { return sqrtf(s); }
-template <typename R> __device__ __forceinline__ R gmin(R a, R b);
-template <> __device__ __forceinline__ double gmin<double>(double a, double b) { return fmin(a, b); }
-template <> __device__ __forceinline__ float gmin<float>(float a, float b) { return fminf(a, b); }
-template <typename R> __device__ __forceinline__ R gmax(R a, R b);
-template <> __device__ __forceinline__ double gmax<double>(double a, double b) { return fmax(a, b); }
-template <> __device__ __forceinline__ float gmax<float>(float a, float b) { return fmaxf(a, b); }
 template <typename R> __device__ __forceinline__ R gfloor(R v);
 template <> __device__ __forceinline__ double gfloor<double>(double v) { return floor(v); }
 template <> __device__ __forceinline__ float gfloor<float>(float v) { return floorf(v); }
@@ -211,70 +205,87 @@ __device__ __forceinline__ float round_through_float(float v) { return v; }
 // SDFMap::getDistWithGradTrilinear, src/sdf_map.cpp:185-242.
 // Out of map (src/sdf_map.cpp:55-69, :187): dist = -1; the reference leaves
 // grad uninitialised there, this build defines it as 0.
-// Branch-free: the corner indices are clamped anyway (:166-174), so the loads
-// are always in bounds and the out-of-map case is a final select.
-// The four (x,y) corner columns of a lookup, each loaded as the pair
-// (D[..][zb], D[..][zb+1]).  Per-axis clamp of the corner indices as in
-// src/sdf_map.cpp:166-174: x0 = clamp(ix), x1 = clamp(ix+1), so x1 = x0 + 1
-// exactly when 0 <= ix <= nx-2 and x1 = x0 otherwise (same for y) — the second
-// column is the first plus a stride that is selected to zero at the borders.
-// WIDE = false (the host checks nx*ny < 2^24, nz < 2^24, field < 4 GiB):
-// 24-bit multiplies (full rate; v_mul_lo_u32 is not) and a uniform base +
-// 32-bit byte offset per lane.  WIDE = true: 64-bit indices, any field.
-// clamp(v, 0, hi) as one v_med3_i32 (the compiler forms med3 only between constants; min(max()) is two instructions,
-// nine times per lane).  Not volatile: free to move and to be eliminated like any arithmetic.  Used by the latency
+// Branch-free: the record index is clamped, so the loads are always in bounds
+// and the out-of-map case is a final select.
+//
+// The field the lookups read is the resident CORNER-RECORD copy (gtop_records.hip), not the
+// boundary's z-fastest buffer: record (cx, cy, cz), cx = ix + 1 in 0 .. nx, cy = iy + 1 in 0 .. ny, cz = level + 1 in
+// 0 .. nz + 1, holds the four (x, y) corners of base index (ix, iy) at z level `level`, every index clamped per axis as
+// getDistance(int,int,int) clamps it (src/sdf_map.cpp:166-174) —
+//     [ D(x0,y0,z), D(x0,y1,z), D(x1,y0,z), D(x1,y1,z) ],  x0 = clamp(ix), x1 = clamp(ix+1), ..., z = clamp(level)
+// — records z-fastest, so the 8 corners of a lookup (:211-219) are the TWO CONSECUTIVE records of levels iz and
+// iz + 1: 64 contiguous bytes in fp64 (four 16-byte loads at one address + 0/16/32/48), 32 in fp32 (two), half a
+// 128-byte line, where the z-fastest field cost four lines of which 16 bytes each were used.  The border clamps
+// live in the records: no border selects, no weight clamp, no z-gradient select here — at a z border both levels hold
+// the same voxels, so the value is v0 + dz*0 and the z-gradient 0 exactly as the reference computes them.
+// The base index of an in-map position is -1 .. n-1 per axis (:201-204); the clamp keeps an out-of-map position's
+// loads inside the buffer.
+// WIDE = false (the host checks (nx+1)(ny+1) < 2^23, nz+2 < 2^23, records below 4 GiB): 24-bit multiply-adds (full
+// rate; v_mul_lo_u32 is not) and a uniform base + 32-bit byte offset per lane.  WIDE = true: 64-bit indices.
+// clamp(v, -1, hi) as one v_med3_i32 (the compiler forms med3 only between constants; min(max()) is two instructions,
+// three times per lookup).  Not volatile: free to move and to be eliminated like any arithmetic.  Used by the latency
 // variant's hand-issued lookups only: in the 168-VGPR bodies the asm's operand constraints cost registers the
-// allocator does not have (17 spilled), there the clamp stays min(max()).
+// allocator does not have, there the clamp stays min(max()).
 __device__ __forceinline__ int clamp_index_med3(int v, int hi) {
 #ifdef GTOP_NO_MED3
-  return min(max(v, 0), hi);
+  return min(max(v, -1), hi);
 #else
   int r;
-  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(hi));
   return r;
 #endif
 }
-__device__ __forceinline__ int clamp_index(int v, int hi) { return min(max(v, 0), hi); }
+__device__ __forceinline__ int clamp_index(int v, int hi) { return min(max(v, -1), hi); }
 
-template <typename R, bool WIDE>
-__device__ __forceinline__ int corner_loads(const GtopKernelArgs<R> &a, int ix, int iy, int iz,
-                                            Pair<R> &p00, Pair<R> &p01, Pair<R> &p10, Pair<R> &p11) {
-  const int nx = a.nx, ny = a.ny, nz = a.nz;
-  const int x0 = clamp_index(ix, nx - 1);
-  const int y0 = clamp_index(iy, ny - 1);
-  const int zb = clamp_index(iz, nz - 2);
-  const bool cx = (unsigned)ix < (unsigned)(nx - 1), cy = (unsigned)iy < (unsigned)(ny - 1);
-  if constexpr (!WIDE) {
-    const char *D = reinterpret_cast<const char *>(a.sdf);
-    constexpr uint32_t esz = (uint32_t)sizeof(R);
-    const uint32_t o00 = (__umul24(__umul24((uint32_t)x0, (uint32_t)ny) + (uint32_t)y0, (uint32_t)nz) + (uint32_t)zb) * esz;
-    const uint32_t sy = cy ? (uint32_t)nz * esz : 0u;
-    const uint32_t sx = cx ? (uint32_t)ny * (uint32_t)nz * esz : 0u;
-    const uint32_t o10 = o00 + sx;
-    p00 = *reinterpret_cast<const Pair<R> *>(D + o00);
-    p01 = *reinterpret_cast<const Pair<R> *>(D + (o00 + sy));
-    p10 = *reinterpret_cast<const Pair<R> *>(D + o10);
-    p11 = *reinterpret_cast<const Pair<R> *>(D + (o10 + sy));
-  } else {
-    const R *D = a.sdf;
-    const size_t i00 = ((size_t)x0 * ny + y0) * nz + zb;
-    const size_t sy = cy ? (size_t)nz : 0, sx = cx ? (size_t)ny * nz : 0;
-    p00 = *reinterpret_cast<const Pair<R> *>(D + i00);
-    p01 = *reinterpret_cast<const Pair<R> *>(D + i00 + sy);
-    p10 = *reinterpret_cast<const Pair<R> *>(D + i00 + sx);
-    p11 = *reinterpret_cast<const Pair<R> *>(D + i00 + sx + sy);
-  }
-  return zb;
+// index of the lookup's first record, less K0 = ((ny+1) + 1)(nz+2) + 1 (the "+1" of every axis, folded into one
+// constant the caller adds): (cx (ny+1) + cy)(nz+2) + cz with cx, cy, cz the clamped BASE indices, -1 .. n-1
+template <bool MED3>
+__device__ __forceinline__ int record_index(int ix, int iy, int iz, int nx, int ny, int nz) {
+  const int cx = MED3 ? clamp_index_med3(ix, nx - 1) : clamp_index(ix, nx - 1);
+  const int cy = MED3 ? clamp_index_med3(iy, ny - 1) : clamp_index(iy, ny - 1);
+  const int cz = MED3 ? clamp_index_med3(iz, nz - 1) : clamp_index(iz, nz - 1);
+  return __mul24(__mul24(cx, ny + 1) + cy, nz + 2) + cz;
 }
 
 // The query is split in two so that a caller can put several lookups in flight
 // before consuming the first: sdf_issue does the index arithmetic and issues the
-// four pair loads, sdf_blend is the trilinear arithmetic on the loaded corners.
+// loads, sdf_blend is the trilinear arithmetic on the loaded corners.
 template <typename R> struct SdfTap {
-  Pair<R> p00, p01, p10, p11;   // (D[x][y][zb], D[x][y][zb+1]) for the four (x,y) corners
-  R dx, dy, dze;                // interpolation weights (dz already folded with the z-border clamp)
-  bool zflat;                   // clamped at a z border (zero z-gradient)
+  R v[8];         // the two records: v000, v010, v100, v110 (level iz), v001, v011, v101, v111 (level iz + 1); v[x][y][z]
+  R dx, dy, dz;   // interpolation weights (sdf_map.cpp:206-209)
 };
+
+typedef double gtop_d2 __attribute__((ext_vector_type(2)));
+typedef float gtop_f4 __attribute__((ext_vector_type(4)));
+
+template <typename R, bool WIDE>
+__device__ __forceinline__ void record_loads(const GtopKernelArgs<R> &a, int ix, int iy, int iz, R (&v)[8]) {
+  const int nx = a.nx, ny = a.ny, nz = a.nz;
+  const char *p;
+  if constexpr (!WIDE) {
+    const int k0 = (ny + 2) * (nz + 2) + 1;
+    const uint32_t off = (uint32_t)(record_index<false>(ix, iy, iz, nx, ny, nz) + k0) * (uint32_t)(4 * sizeof(R));
+    p = reinterpret_cast<const char *>(a.sdf) + off;
+  } else {
+    const size_t idx = ((size_t)(clamp_index(ix, nx - 1) + 1) * (size_t)(ny + 1) + (size_t)(clamp_index(iy, ny - 1) + 1)) *
+                           (size_t)(nz + 2) + (size_t)(clamp_index(iz, nz - 1) + 1);
+    p = reinterpret_cast<const char *>(a.sdf + 4 * idx);
+  }
+  if constexpr (sizeof(R) == 8) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const gtop_d2 t = *reinterpret_cast<const gtop_d2 *>(p + 16 * q);
+      v[2 * q] = t.x;
+      v[2 * q + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const gtop_f4 t = *reinterpret_cast<const gtop_f4 *>(p + 16 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  }
+}
 
 // isInMap (sdf_map.cpp:55-69) of one position, exactly as the reference tests it
 template <typename R>
@@ -296,36 +307,28 @@ __device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, const
   // posToIndex(pos - 0.5 res)  (:201-204 -> :71-74)
   const R tx = (px - half) - box.org[0], ty = (py - half) - box.org[1], tz = (pz - half) - box.org[2];
   const R ux = tx * rinv, uy = ty * rinv, uz = tz * rinv;
-  const R fx = gfloor(ux), fy = gfloor(uy);
-  const int ix = (int)fx, iy = (int)fy, iz = (int)gfloor(uz);
+  const R fx = gfloor(ux), fy = gfloor(uy), fz = gfloor(uz);
+  record_loads<R, WIDE>(a, (int)fx, (int)fy, (int)fz, tp.v);
   // indexToPos (:76-78) and diff (:209): (pos - centre(idx)) / res is the fractional
   // part of u (equal up to a few ulp of u, ~1e-14 of a voxel).  Written as the fused form the compiler
   // contracts `u - floor(u)` to where it can: every body, however it is scheduled, takes the same bits.
   tp.dx = gfma(tx, rinv, -fx);
   tp.dy = gfma(ty, rinv, -fy);
-
-  // z is the fastest axis, so the two z-corners of each (x,y) column are one
-  // 2-element load; the clamp at the z borders becomes a clamp of the weight.
-  const int zb = corner_loads<R, WIDE>(a, ix, iy, iz, tp.p00, tp.p01, tp.p10, tp.p11);
-  // At a z border both z-corners clamp to the same voxel (:166-174); with the
-  // pair (D[zb], D[zb+1]) in hand that is dz := 0 (iz < 0) or dz := 1
-  // (iz > nz-2) — i.e. uz - zb clamped to [0,1] — and a zero z-gradient.
-  tp.dze = gmin(gmax(gfma(tz, rinv, -(R)zb), (R)0), (R)1);
-  tp.zflat = iz != zb;
+  tp.dz = gfma(tz, rinv, -fz);
   return tp;
 }
 
-// The same with the four pair loads issued by hand (fp64, 32-bit offsets): the lone-wavefront body wants all of a
+// The same with the four 16-byte loads issued by hand (fp64, 32-bit offsets): the lone-wavefront body wants all of a
 // lane's corner loads in flight BEFORE the arithmetic that does not need them, and the compiler — free to sink
 // side-effect-free loads of a read-only noalias field, and keen to, at 232 VGPRs — put each sample's loads right in
 // front of their use (round 2: the first sample's loads were waited for 20 instructions after their issue, whatever
 // scheduling barriers said).  A volatile asm keeps its place among the phase fences; the compiler does not count
-// these loads, so the caller waits for them itself (gtop_wait_pairs) before it reads `raw`.
-typedef double gtop_d2 __attribute__((ext_vector_type(2)));
-
+// these loads, so the caller waits for them itself (gtop_wait_pairs) before it reads `raw`
+// (tools/kernel_resources.py check_asm_loads walks the ISA: nothing names their registers before that wait).
+template <int BYTE_OFF>
 __device__ __forceinline__ gtop_d2 asm_load_pair(const void *base, uint32_t byte_off) {
   gtop_d2 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base));
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(byte_off), "s"(base), "n"(BYTE_OFF));
   return v;
 }
 
@@ -345,26 +348,18 @@ __device__ __forceinline__ SdfTap<double> sdf_issue_asm(const GtopKernelArgs<dou
   const R rinv = box.rinv, half = box.half;
   const R tx = (px - half) - box.org[0], ty = (py - half) - box.org[1], tz = (pz - half) - box.org[2];
   const R ux = tx * rinv, uy = ty * rinv, uz = tz * rinv;
-  const R fx = gfloor(ux), fy = gfloor(uy);
-  const int ix = (int)fx, iy = (int)fy, iz = (int)gfloor(uz);
+  const R fx = gfloor(ux), fy = gfloor(uy), fz = gfloor(uz);
   tp.dx = gfma(tx, rinv, -fx);
   tp.dy = gfma(ty, rinv, -fy);
-  // corner_loads<double, false>, loads by hand
+  tp.dz = gfma(tz, rinv, -fz);
+  // record_loads<double, false>, loads by hand: one address, four immediate offsets
   const int nx = a.nx, ny = a.ny, nz = a.nz;
-  const int x0 = clamp_index_med3(ix, nx - 1);
-  const int y0 = clamp_index_med3(iy, ny - 1);
-  const int zb = clamp_index_med3(iz, nz - 2);
-  const bool cx = (unsigned)ix < (unsigned)(nx - 1), cy = (unsigned)iy < (unsigned)(ny - 1);
-  const uint32_t o00 = (__umul24(__umul24((uint32_t)x0, (uint32_t)ny) + (uint32_t)y0, (uint32_t)nz) + (uint32_t)zb) * 8u;
-  const uint32_t sy = cy ? (uint32_t)nz * 8u : 0u;
-  const uint32_t sx = cx ? (uint32_t)ny * (uint32_t)nz * 8u : 0u;
-  const uint32_t o10 = o00 + sx;
-  raw[0] = asm_load_pair(a.sdf, o00);
-  raw[1] = asm_load_pair(a.sdf, o00 + sy);
-  raw[2] = asm_load_pair(a.sdf, o10);
-  raw[3] = asm_load_pair(a.sdf, o10 + sy);
-  tp.dze = gmin(gmax(gfma(tz, rinv, -(R)zb), (R)0), (R)1);
-  tp.zflat = iz != zb;
+  const int k0 = (ny + 2) * (nz + 2) + 1;
+  const uint32_t off = (uint32_t)(record_index<true>((int)fx, (int)fy, (int)fz, nx, ny, nz) + k0) * 32u;
+  raw[0] = asm_load_pair<0>(a.sdf, off);
+  raw[1] = asm_load_pair<16>(a.sdf, off);
+  raw[2] = asm_load_pair<32>(a.sdf, off);
+  raw[3] = asm_load_pair<48>(a.sdf, off);
   return tp;
 }
 
@@ -375,21 +370,21 @@ __device__ __forceinline__ SdfTap<double> sdf_issue_asm(const GtopKernelArgs<dou
 // (:231-239) into the weight that multiplies it.
 template <typename R>
 __device__ __forceinline__ R sdf_blend(const SdfTap<R> &tp, R &gx, R &gy, R &gz) {
-  const R dx = tp.dx, dy = tp.dy, dze = tp.dze;
+  const R dx = tp.dx, dy = tp.dy, dz = tp.dz;
   // values[x][y][z]
-  const R v000 = tp.p00.x, v001 = tp.p00.y, v010 = tp.p01.x, v011 = tp.p01.y;
-  const R d00 = tp.p10.x - v000, d01 = tp.p10.y - v001;   // x-differences of the four (y,z) edges
-  const R d10 = tp.p11.x - v010, d11 = tp.p11.y - v011;
+  const R v000 = tp.v[0], v010 = tp.v[1], v001 = tp.v[4], v011 = tp.v[5];
+  const R d00 = tp.v[2] - v000, d01 = tp.v[6] - v001;   // x-differences of the four (y,z) edges
+  const R d10 = tp.v[3] - v010, d11 = tp.v[7] - v011;
   const R v00 = gfma(dx, d00, v000), v01 = gfma(dx, d01, v001);   // :221-224
   const R v10 = gfma(dx, d10, v010), v11 = gfma(dx, d11, v011);
   const R e0 = v10 - v00, e1 = v11 - v01;                          // y-differences
   const R v0 = gfma(dy, e0, v00), v1 = gfma(dy, e1, v01);          // :226-227
   const R dd = v1 - v0;                                            // z-difference (:231)
-  const R dist = gfma(dze, dd, v0);                                // :229
-  gy = gfma(dze, e1 - e0, e0);                                     // :232-233
+  const R dist = gfma(dz, dd, v0);                                 // :229
+  gy = gfma(dz, e1 - e0, e0);                                      // :232-233
   const R h0 = gfma(dy, d10 - d00, d00), h1 = gfma(dy, d11 - d01, d01);
-  gx = gfma(dze, h1 - h0, h0);                                     // :234-239
-  gz = tp.zflat ? (R)0 : dd;
+  gx = gfma(dz, h1 - h0, h0);                                      // :234-239
+  gz = dd;   // (at a z border both levels hold the same voxels: 0, as :231 gives it)
   return dist;   // (out of the map: the caller overrides value and gradient, sdf_map.cpp:187)
 }
 
@@ -429,27 +424,17 @@ __device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 
   const f2 h = splat(0.5f);
   const f2 dx = (px - ((fx + h) * res + ox)) * rinv;
   const f2 dy = (py - ((fy + h) * res + oy)) * rinv;
-  f2 dz = (pz - ((fz + h) * res + oz)) * rinv;
+  const f2 dz = (pz - ((fz + h) * res + oz)) * rinv;
 
-  const int nz = a.nz;
-  Pair<float> p00[2], p01[2], p10[2], p11[2];
-  bool zflat[2];
+  // the two records of each sample (record_loads): border clamps are in the records, dz is the plain fraction
+  float c8[2][8];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int ix = (int)(c ? fx.y : fx.x), iy = (int)(c ? fy.y : fy.x), iz = (int)(c ? fz.y : fz.x);
-    corner_loads<float, WIDE>(a, ix, iy, iz, p00[c], p01[c], p10[c], p11[c]);
-    // z border (:166-174): both z-corners clamp to the same voxel.  With the
-    // pair (D[zb], D[zb+1]) loaded, that is dz := 0 (iz = -1) or 1 (iz = nz-1)
-    // and a zero z-gradient.
-    const bool lo = iz < 0, hi = iz > nz - 2;
-    zflat[c] = lo | hi;
-    const float dzc = lo ? 0.0f : (hi ? 1.0f : (c ? dz.y : dz.x));
-    if (c) dz.y = dzc; else dz.x = dzc;
-  }
-  const f2 v000 = {p00[0].x, p00[1].x}, v001 = {p00[0].y, p00[1].y};
-  const f2 v010 = {p01[0].x, p01[1].x}, v011 = {p01[0].y, p01[1].y};
-  const f2 v100 = {p10[0].x, p10[1].x}, v101 = {p10[0].y, p10[1].y};
-  const f2 v110 = {p11[0].x, p11[1].x}, v111 = {p11[0].y, p11[1].y};
+  for (int c = 0; c < 2; ++c)
+    record_loads<float, WIDE>(a, (int)(c ? fx.y : fx.x), (int)(c ? fy.y : fy.x), (int)(c ? fz.y : fz.x), c8[c]);
+  const f2 v000 = {c8[0][0], c8[1][0]}, v010 = {c8[0][1], c8[1][1]};
+  const f2 v100 = {c8[0][2], c8[1][2]}, v110 = {c8[0][3], c8[1][3]};
+  const f2 v001 = {c8[0][4], c8[1][4]}, v011 = {c8[0][5], c8[1][5]};
+  const f2 v101 = {c8[0][6], c8[1][6]}, v111 = {c8[0][7], c8[1][7]};
   // difference form, gradient unscaled (per voxel): see sdf_blend
   const f2 d00 = v100 - v000, d01 = v101 - v001, d10 = v110 - v010, d11 = v111 - v011;
   const f2 v00 = pk_fma(dx, d00, v000), v01 = pk_fma(dx, d01, v001);   // :221-224
@@ -461,9 +446,7 @@ __device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 
   gy = pk_fma(dz, e1 - e0, e0);                                        // :232-233
   const f2 h0 = pk_fma(dy, d10 - d00, d00), h1 = pk_fma(dy, d11 - d01, d01);
   gx = pk_fma(dz, h1 - h0, h0);                                        // :234-239
-  gz = dd;
-  if (zflat[0]) gz.x = 0.0f;
-  if (zflat[1]) gz.y = 0.0f;
+  gz = dd;   // (0 at a z border: both levels hold the same voxels)
   return dist;
 }
 
@@ -951,7 +934,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // scheduling barriers.  Throughput regime (MINW = 3): one sample at a time — other wavefronts cover the loads,
     // and only one sample's corners are live (the 168-VGPR budget of a third wavefront).
     constexpr int CH = (MINW <= 2) ? SPL : 1;
-    constexpr int kUnrollJ = SPL <= 3 ? SPL : 1;   // six samples per lane stay a loop (code size)
+    constexpr int kUnrollJ = (SPL <= 3 && MINW <= 2) ? SPL : 1;   // one sample at a time (MINW = 3): a loop (code size; unrolled, the three-sample body spills at 168 VGPRs)
 #ifndef GTOP_ASM_LOADS
 #define GTOP_ASM_LOADS 1
 #endif
@@ -1064,10 +1047,11 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
           if (CH - 1 - c == 2) gtop_wait_pairs<8>(raw[c], acc[3], acc[17]);
           else if (CH - 1 - c == 1) gtop_wait_pairs<4>(raw[c], acc[3], acc[17]);
           else gtop_wait_pairs<0>(raw[c], acc[3], acc[17]);
-          taps[c].p00.x = raw[c][0].x; taps[c].p00.y = raw[c][0].y;
-          taps[c].p01.x = raw[c][1].x; taps[c].p01.y = raw[c][1].y;
-          taps[c].p10.x = raw[c][2].x; taps[c].p10.y = raw[c][2].y;
-          taps[c].p11.x = raw[c][3].x; taps[c].p11.y = raw[c][3].y;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            taps[c].v[2 * q] = raw[c][q].x;
+            taps[c].v[2 * q + 1] = raw[c][q].y;
+          }
         }
         const R t = ts[MINW <= 2 ? j0 + c : 0];
         const R *vel = vels[c];
@@ -1289,10 +1273,10 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
 
 }  // namespace
 
-// WIDE = false needs 24-bit row/column counts and a field below 4 GiB (corner_loads)
+// WIDE = false needs 24-bit (signed) multiplicands and corner records below 4 GiB (record_loads)
 bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
-  const unsigned long long nvox = (unsigned long long)nx * ny * nz;
-  return (unsigned long long)nx * ny < (1ull << 24) && nz < (1 << 24) && (nvox + 2) * elem < (1ull << 32);
+  const unsigned long long nrec = (unsigned long long)(nx + 1) * (ny + 1) * (nz + 2);
+  return (unsigned long long)(nx + 1) * (ny + 1) < (1ull << 23) && nz + 2 < (1 << 23) && nrec * 4 * elem < (1ull << 32);
 }
 
 #ifndef GTOP_TWO_PER_WAVE_F64_FROM

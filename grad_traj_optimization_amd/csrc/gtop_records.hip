@@ -1,0 +1,110 @@
+// gtop_records.hip — the resident, gather-friendly copy of the distance field: CORNER RECORDS.
+//
+// The boundary keeps the reference's layout, `distance_buffer[x*ny*nz + y*nz + z]` (src/sdf_map.cpp:172-173): that is
+// what gtop_set_sdf / gtop_get_sdf exchange and what the ESDF builder writes.  But getDistWithGradTrilinear
+// (src/sdf_map.cpp:185-242) reads the 8 corners of a cell, and in that layout they are four (z, z+1) pairs in four
+// different 128-byte lines: a lookup touches 4.25 lines to use 64 bytes (round 3, configs[4]: 1.69 M line requests
+// per launch, the memory system's line rate the bound; the f4 query kernel 4.24 lines per query).  So the lookups read
+// a second, derived copy laid out for them (the "texture-style" gather of the north_star):
+//
+//   record (cx, cy, cz), cx = ix + 1 in 0 .. nx, cy = iy + 1 in 0 .. ny, cz = level + 1 in 0 .. nz + 1
+//     = [ D(x0,y0,z), D(x0,y1,z), D(x1,y0,z), D(x1,y1,z) ]
+//       x0 = clamp(ix), x1 = clamp(ix + 1), y0 = clamp(iy), y1 = clamp(iy + 1), z = clamp(level)
+//       (the per-axis index clamp of getDistance(int,int,int), src/sdf_map.cpp:166-174; ix, iy = -1 .. n-1 are the
+//        base indices an in-map position can have, :201-204; level = -1 .. nz)
+//   records are z-fastest: index (cx (ny+1) + cy)(nz+2) + cz.
+//
+// The 8 corners of base index (ix, iy, iz) are then the two CONSECUTIVE records of levels iz and iz + 1: 64
+// contiguous bytes in fp64, 32 in fp32 — half a line (a lookup straddles two lines one time in four: 1.25 lines per
+// lookup), fetched with one address and immediate offsets, the border clamps already applied.  Cost: 4x the field's
+// bytes (200^3: 262 MB fp64, 400^3: 2.1 GB — 288 GB of HBM) and one streaming pass per map update (below).  Neighbouring
+// cells along z share three quarters of their bytes, so a trajectory's consecutive samples still reuse lines.
+//
+// The builder: one lane per record, lanes along z (the source rows are read coalesced, each record is one 32-byte
+// (fp64) or 16-byte (fp32) store, a wavefront writes 2 KB / 1 KB of whole lines), record slab cx on XCD cx mod 8 so
+// that the two source slabs a record slab reads stay in that XCD's L2.  A window form rebuilds only the records a
+// changed voxel box touches (gtop_update_sdf_map_window).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gtop_kernels.h"
+
+namespace {
+
+template <typename D> struct Rec4;
+template <> struct Rec4<double> { double a, b, c, d; } __attribute__((aligned(32)));
+template <> struct Rec4<float> { float a, b, c, d; } __attribute__((aligned(16)));
+
+// records cx in [cx0, cx1], cy in [cy0, cy1], cz in [cz0, cz1] (inclusive); the whole field: 0..nx, 0..ny, 0..nz+1
+template <typename S, typename D>
+__global__ void __launch_bounds__(256)
+records_kernel(const S *__restrict__ field, D *__restrict__ rec, int nx, int ny, int nz, int cx0, int cx1, int cy0,
+               int cy1, int cz0, int cz1, int blocks_per_slab) {
+  const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+  const int slab = q / blocks_per_slab, within = q - slab * blocks_per_slab;
+  // slab cx on XCD cx mod 8: the first slab of the window that lives on this XCD, then every eighth
+  const int first = cx0 + ((xcd - cx0) & 7);
+  const int cx = first + 8 * slab;
+  if (cx > cx1) return;
+  const int wz = cz1 - cz0 + 1, wy = cy1 - cy0 + 1;
+  const int flat = within * 256 + (int)threadIdx.x;
+  if (flat >= wy * wz) return;
+  const int ry = flat / wz, cy = cy0 + ry, cz = cz0 + (flat - ry * wz);
+  const int x0 = min(max(cx - 1, 0), nx - 1), x1 = min(cx, nx - 1);
+  const int y0 = min(max(cy - 1, 0), ny - 1), y1 = min(cy, ny - 1);
+  const int z = min(max(cz - 1, 0), nz - 1);
+  const size_t r00 = ((size_t)x0 * ny + y0) * nz + z, r01 = ((size_t)x0 * ny + y1) * nz + z;
+  const size_t r10 = ((size_t)x1 * ny + y0) * nz + z, r11 = ((size_t)x1 * ny + y1) * nz + z;
+  Rec4<D> out;
+  out.a = (D)field[r00];
+  out.b = (D)field[r01];
+  out.c = (D)field[r10];
+  out.d = (D)field[r11];
+  const size_t ri = ((size_t)cx * (ny + 1) + cy) * (nz + 2) + cz;
+  reinterpret_cast<Rec4<D> *>(rec)[ri] = out;
+}
+
+template <typename S, typename D>
+hipError_t launch_records(const GtopGrid &g, const S *field, D *rec, const int lo[3], const int hi[3], hipStream_t s) {
+  const int wx = hi[0] - lo[0] + 1, wy = hi[1] - lo[1] + 1, wz = hi[2] - lo[2] + 1;
+  if (wx <= 0 || wy <= 0 || wz <= 0) return hipSuccess;
+  const long long per_slab = ((long long)wy * wz + 255) / 256;
+  const long long slabs_per_xcd = (wx + 7) / 8;
+  const long long grid = 8 * slabs_per_xcd * per_slab;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((records_kernel<S, D>), dim3((unsigned)grid), dim3(256), 0, s, field, rec, g.nx, g.ny, g.nz, lo[0],
+                     hi[0], lo[1], hi[1], lo[2], hi[2], (int)per_slab);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t gtop_record_count(const GtopGrid &g) { return (size_t)(g.nx + 1) * (g.ny + 1) * (g.nz + 2); }
+
+// Records of the voxel box [vlo, vhi] (inclusive voxel indices; NULL = the whole field): every record that holds one
+// of its voxels — voxel x sits in records cx = x and x + 1 (and, clamped, in the border records beyond the grid's
+// first / last voxel), likewise y; level z in cz = z + 1 (and in the padding levels at the z ends).
+template <typename S, typename D>
+hipError_t gtop_launch_build_records(const GtopGrid &g, const S *field, D *rec, const int *vlo, const int *vhi,
+                                     hipStream_t stream) {
+  const int n[3] = {g.nx, g.ny, g.nz};
+  int lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) {
+    const int a = vlo ? vlo[k] : 0, b = vhi ? vhi[k] : n[k] - 1;
+    if (k < 2) {
+      lo[k] = a <= 0 ? 0 : a;              // voxel a is x1 of record a and x0 of record a + 1; voxel 0 also fills record 0
+      hi[k] = b >= n[k] - 1 ? n[k] : b + 1;
+    } else {
+      lo[k] = a <= 0 ? 0 : a + 1;          // level z is record z + 1; level 0 also fills the padding record 0
+      hi[k] = b >= n[k] - 1 ? n[k] + 1 : b + 1;
+    }
+  }
+  return launch_records<S, D>(g, field, rec, lo, hi, stream);
+}
+
+template hipError_t gtop_launch_build_records<double, double>(const GtopGrid &, const double *, double *, const int *,
+                                                              const int *, hipStream_t);
+template hipError_t gtop_launch_build_records<double, float>(const GtopGrid &, const double *, float *, const int *,
+                                                             const int *, hipStream_t);
+template hipError_t gtop_launch_build_records<float, float>(const GtopGrid &, const float *, float *, const int *,
+                                                            const int *, hipStream_t);

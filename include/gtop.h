@@ -87,7 +87,10 @@ int gtop_set_params(gtop_ctx *ctx, const gtop_params *p);
 /* Replaces GradTrajOptimizer::initSDFMap + the distance_buffer that
  * updateSDFMap leaves behind (src/grad_traj_optimizer.cpp:112-126,
  * src/sdf_map.cpp:3-24).  `dist_host` holds nx*ny*nz doubles; it is uploaded
- * to HBM (an fp32 copy is made on the device for the GTOP_F32 path).
+ * to HBM; the corner records every lookup reads (csrc/gtop_records.hip: the
+ * 8 corners of a cell as 64 contiguous bytes, border clamps applied, 4x the
+ * field's bytes) are derived from it on the device, fp32 ones at the first
+ * fp32 use.
  * `map_size` may be NULL (then max_range = origin + grid*res); when given,
  * max_range = origin + map_size as src/sdf_map.cpp:12 has it.
  * Requires nx, ny, nz >= 2 and nx*ny*nz < 2^31. */
@@ -95,8 +98,13 @@ int gtop_set_sdf(gtop_ctx *ctx, const double *dist_host, int nx, int ny, int nz,
                  const double origin[3], const double *map_size,
                  double resolution);
 
-/* Same, from a distance field already resident in HBM (dtype says which).
- * The buffer is borrowed, not copied; it must outlive its use. */
+/* Same, from a distance field already resident in HBM (dtype says which; the
+ * caller has synchronised whatever wrote it).  The buffer is borrowed as the
+ * boundary copy — gtop_get_sdf and the coarse voxel query read it in place, so
+ * it must outlive its use — and the gather-friendly corner records the lookups
+ * read (csrc/gtop_records.hip) are derived from it AT THIS CALL: after writing
+ * to the buffer, call again.  A GTOP_F64 field serves evaluations of both
+ * precisions, a GTOP_F32 field fp32 evaluations only. */
 int gtop_set_sdf_device(gtop_ctx *ctx, int dtype, const void *dist_dev, int nx,
                         int ny, int nz, const double origin[3],
                         const double *map_size, double resolution);

@@ -488,8 +488,9 @@ def test_full_size_400_cube_m12(gtop, oracle_mod):
 
 
 def test_borrowed_device_field(scene, oracle_mod, gtop):
-    """gtop_set_sdf_device: a distance field that already lives in HBM (fp64 or fp32) is
-    used in place, not copied; the other precision is then unavailable (GTOP_ERR_STATE)."""
+    """gtop_set_sdf_device: a distance field that already lives in HBM (fp64 or fp32) is borrowed as the boundary
+    copy; the corner records the lookups read are derived from it at the call.  From an fp64 field both precisions
+    follow (round 4); an fp32 field serves fp32 evaluations only (GTOP_ERR_STATE for fp64: no fp64 data)."""
     import torch
     mp, ctx0, sdf = scene
     dev = torch.device("cuda:0")
@@ -507,9 +508,16 @@ def test_borrowed_device_field(scene, oracle_mod, gtop):
         rc, rg = scenes.rel_err(c.double().cpu().numpy(), g.double().cpu().numpy(), c_ref, g_ref)
         assert rc <= tol and rg <= tol, (td, rc, rg)
         other = torch.float32 if td == torch.float64 else torch.float64
-        with pytest.raises(gtop.GtopError) as e:
-            ctx.eval_device(x.to(other), Df.to(other), T.to(other))
-        assert e.value.code == 4
+        if td == torch.float64:
+            c2, g2 = ctx.eval_device(x.to(other), Df.to(other), T.to(other))
+            torch.cuda.synchronize()
+            rc, rg = scenes.rel_err(c2.double().cpu().numpy(), g2.double().cpu().numpy(), c_ref, g_ref)
+            assert rc <= TOL32 and rg <= TOL32, (other, rc, rg)
+            assert np.array_equal(ctx.get_sdf().reshape(-1), sdf.dist)       # read back from the borrowed buffer itself
+        else:
+            with pytest.raises(gtop.GtopError) as e:
+                ctx.eval_device(x.to(other), Df.to(other), T.to(other))
+            assert e.value.code == 4
 
 
 def test_spatial_order_is_a_pure_permutation(scene, gtop):
