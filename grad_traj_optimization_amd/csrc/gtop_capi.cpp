@@ -200,10 +200,10 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
 // Corner records of the fp64 field on stream `s` (the whole field, or the voxel box [vlo, vhi]); the fp32 records too
 // when they are wanted now, otherwise they are marked stale and the first fp32 use builds them.
 int build_records_on_stream(gtop_ctx *c, hipStream_t s, bool fp32_now, const int *vlo = nullptr, const int *vhi = nullptr) {
-  HIPCHK(c, (gtop_launch_build_records<double, double>(c->grid, c->sdf64, c->rec64, vlo, vhi, s)));
+  // (both precisions in one pass over the field when both are wanted)
+  HIPCHK(c, (gtop_launch_build_records<double, double>(c->grid, c->sdf64, c->rec64, fp32_now ? c->rec32 : nullptr, vlo, vhi, s)));
   c->rec64_ok = true;
   if (fp32_now) {
-    HIPCHK(c, (gtop_launch_build_records<double, float>(c->grid, c->sdf64, c->rec32, vlo, vhi, s)));
     c->rec32_ok = true;
     c->rec32_stale = false;
   } else {
@@ -220,7 +220,7 @@ int fp32_records_ready(gtop_ctx *c, hipStream_t s) {
   if (!c->rec32_stale || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
   // only a synchronous entry point (gtop_set_sdf, gtop_init_sdf_map, gtop_update_sdf_map) leaves the records stale,
   // and it has synchronised: the fp64 field is complete whatever stream `s` is
-  HIPCHK(c, (gtop_launch_build_records<double, float>(c->grid, c->sdf64, c->rec32, nullptr, nullptr, s)));
+  HIPCHK(c, (gtop_launch_build_records<double, float>(c->grid, c->sdf64, c->rec32, nullptr, nullptr, nullptr, s)));
   c->rec32_ok = true;
   c->rec32_stale = false;
   return GTOP_OK;
@@ -383,7 +383,7 @@ int gtop_set_sdf_device(gtop_ctx *c, int dtype, const void *dist_dev, int nx, in
     if ((rc = build_records_on_stream(c, c->stream, c->fp32_in_use))) return rc;
   } else {
     c->sdf32b = static_cast<const float *>(dist_dev);
-    HIPCHK(c, (gtop_launch_build_records<float, float>(c->grid, c->sdf32b, c->rec32, nullptr, nullptr, c->stream)));
+    HIPCHK(c, (gtop_launch_build_records<float, float>(c->grid, c->sdf32b, c->rec32, nullptr, nullptr, nullptr, c->stream)));
     c->rec32_ok = true;
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));

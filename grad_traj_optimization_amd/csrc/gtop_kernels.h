@@ -99,11 +99,11 @@ hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tm
 
 // ---- corner records (gtop_records.hip): the gather-friendly resident copy the lookups read ----
 size_t gtop_record_count(const GtopGrid &g);   // (nx+1)(ny+1)(nz+2) records of 4 values
-// S -> D in {double -> double, double -> float, float -> float}; vlo / vhi: inclusive voxel box whose records are
-// rebuilt (NULL = the whole field)
+// S -> D in {double -> double, double -> float, float -> float}; rec32 (may be NULL): the fp32 records too, in the
+// same pass; vlo / vhi: inclusive voxel box whose records are rebuilt (NULL = the whole field)
 template <typename S, typename D>
-hipError_t gtop_launch_build_records(const GtopGrid &g, const S *field, D *rec, const int *vlo, const int *vhi,
-                                     hipStream_t stream);
+hipError_t gtop_launch_build_records(const GtopGrid &g, const S *field, D *rec, float *rec32, const int *vlo,
+                                     const int *vhi, hipStream_t stream);
 
 // the optimizer loop: st.iters x {cost/gradient at st.xcur, CCSA-MMA update} per trajectory in one launch (fp64; a plan
 // made with for_optimizer = true); honours st.x0_init / st.out_*

@@ -20,9 +20,9 @@
 // bytes (200^3: 262 MB fp64, 400^3: 2.1 GB — 288 GB of HBM) and one streaming pass per map update (below).  Neighbouring
 // cells along z share three quarters of their bytes, so a trajectory's consecutive samples still reuse lines.
 //
-// The builder: one lane per record, lanes along z (the source rows are read coalesced, each record is one 32-byte
-// (fp64) or 16-byte (fp32) store, a wavefront writes 2 KB / 1 KB of whole lines), record slab cx on XCD cx mod 8 so
-// that the two source slabs a record slab reads stay in that XCD's L2.  A window form rebuilds only the records a
+// The builder: one lane per HALF record, lanes along z (the source rows are read coalesced; every store instruction
+// of a wavefront writes one contiguous kilobyte of whole lines), record slab cx on XCD cx mod 8 so that the two
+// source slabs a record slab reads stay in that XCD's L2.  A window form rebuilds only the records a
 // changed voxel box touches (gtop_update_sdf_map_window).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,49 +31,64 @@
 
 namespace {
 
-template <typename D> struct Rec4;
-template <> struct Rec4<double> { double a, b, c, d; } __attribute__((aligned(32)));
-template <> struct Rec4<float> { float a, b, c, d; } __attribute__((aligned(16)));
+template <typename D> struct Half2;   // half a record: the two y-corners of one x column
+template <> struct Half2<double> { double lo, hi; } __attribute__((aligned(16)));
+template <> struct Half2<float> { float lo, hi; } __attribute__((aligned(8)));
 
-// records cx in [cx0, cx1], cy in [cy0, cy1], cz in [cz0, cz1] (inclusive); the whole field: 0..nx, 0..ny, 0..nz+1
+// records cx in [cx0, cx1], cy in [cy0, cy1], cz in [cz0, cz1] (inclusive); the whole field: 0..nx, 0..ny, 0..nz+1.
+// A lane owns HALF a record — the pair (D(x_h, y0, z), D(x_h, y1, z)) of x column h of record (cx, cy, cz) — for kTY
+// consecutive cy: lanes 2j and 2j+1 are the two halves of one record, consecutive lane pairs consecutive cz, so every
+// store instruction of a wavefront writes one contiguous kilobyte (fp64; 512 bytes fp32) of whole lines (a lane per
+// whole record made each 16-byte store instruction touch every line of a 2 KB span half: 3 TB/s of writes), and the
+// row it loaded as the upper corner of one record is the lower corner of the next: one 8-byte load per 16 bytes stored.
+// rec32 != nullptr: the fp32 records of the same field in the same pass (one read of the field for both).
+constexpr int kTY = 8;
+
 template <typename S, typename D>
 __global__ void __launch_bounds__(256)
-records_kernel(const S *__restrict__ field, D *__restrict__ rec, int nx, int ny, int nz, int cx0, int cx1, int cy0,
-               int cy1, int cz0, int cz1, int blocks_per_slab) {
+records_kernel(const S *__restrict__ field, D *__restrict__ rec, float *__restrict__ rec32, int nx, int ny, int nz, int cx0,
+               int cx1, int cy0, int cy1, int cz0, int cz1, int blocks_per_slab) {
   const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
   const int slab = q / blocks_per_slab, within = q - slab * blocks_per_slab;
   // slab cx on XCD cx mod 8: the first slab of the window that lives on this XCD, then every eighth
   const int first = cx0 + ((xcd - cx0) & 7);
   const int cx = first + 8 * slab;
   if (cx > cx1) return;
-  const int wz = cz1 - cz0 + 1, wy = cy1 - cy0 + 1;
+  const int wz2 = 2 * (cz1 - cz0 + 1), wy = cy1 - cy0 + 1, tiles_y = (wy + kTY - 1) / kTY;
   const int flat = within * 256 + (int)threadIdx.x;
-  if (flat >= wy * wz) return;
-  const int ry = flat / wz, cy = cy0 + ry, cz = cz0 + (flat - ry * wz);
-  const int x0 = min(max(cx - 1, 0), nx - 1), x1 = min(cx, nx - 1);
-  const int y0 = min(max(cy - 1, 0), ny - 1), y1 = min(cy, ny - 1);
+  if (flat >= tiles_y * wz2) return;
+  const int ty = flat / wz2, c = flat - ty * wz2, h = c & 1, cz = cz0 + (c >> 1);
+  const int cya = cy0 + ty * kTY, cyb = min(cya + kTY - 1, cy1);
+  const int x = h ? min(cx, nx - 1) : min(max(cx - 1, 0), nx - 1);
   const int z = min(max(cz - 1, 0), nz - 1);
-  const size_t r00 = ((size_t)x0 * ny + y0) * nz + z, r01 = ((size_t)x0 * ny + y1) * nz + z;
-  const size_t r10 = ((size_t)x1 * ny + y0) * nz + z, r11 = ((size_t)x1 * ny + y1) * nz + z;
-  Rec4<D> out;
-  out.a = (D)field[r00];
-  out.b = (D)field[r01];
-  out.c = (D)field[r10];
-  out.d = (D)field[r11];
-  const size_t ri = ((size_t)cx * (ny + 1) + cy) * (nz + 2) + cz;
-  reinterpret_cast<Rec4<D> *>(rec)[ri] = out;
+  const S *col = field + (size_t)x * ny * nz + z;
+  S lo = col[(size_t)min(max(cya - 1, 0), ny - 1) * nz];
+  size_t hi_at = 2 * (((size_t)cx * (ny + 1) + cya) * (nz + 2) + cz) + h;   // in half records
+  for (int cy = cya; cy <= cyb; ++cy, hi_at += 2 * (size_t)(nz + 2)) {
+    const S hi = col[(size_t)min(cy, ny - 1) * nz];
+    Half2<D> out;
+    out.lo = (D)lo; out.hi = (D)hi;
+    reinterpret_cast<Half2<D> *>(rec)[hi_at] = out;
+    if (rec32) {
+      Half2<float> o32;
+      o32.lo = (float)lo; o32.hi = (float)hi;
+      reinterpret_cast<Half2<float> *>(rec32)[hi_at] = o32;
+    }
+    lo = hi;
+  }
 }
 
 template <typename S, typename D>
-hipError_t launch_records(const GtopGrid &g, const S *field, D *rec, const int lo[3], const int hi[3], hipStream_t s) {
+hipError_t launch_records(const GtopGrid &g, const S *field, D *rec, float *rec32, const int lo[3], const int hi[3],
+                          hipStream_t s) {
   const int wx = hi[0] - lo[0] + 1, wy = hi[1] - lo[1] + 1, wz = hi[2] - lo[2] + 1;
   if (wx <= 0 || wy <= 0 || wz <= 0) return hipSuccess;
-  const long long per_slab = ((long long)wy * wz + 255) / 256;
+  const long long per_slab = ((long long)((wy + kTY - 1) / kTY) * 2 * wz + 255) / 256;
   const long long slabs_per_xcd = (wx + 7) / 8;
   const long long grid = 8 * slabs_per_xcd * per_slab;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((records_kernel<S, D>), dim3((unsigned)grid), dim3(256), 0, s, field, rec, g.nx, g.ny, g.nz, lo[0],
-                     hi[0], lo[1], hi[1], lo[2], hi[2], (int)per_slab);
+  hipLaunchKernelGGL((records_kernel<S, D>), dim3((unsigned)grid), dim3(256), 0, s, field, rec, rec32, g.nx, g.ny, g.nz,
+                     lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], (int)per_slab);
   return hipGetLastError();
 }
 
@@ -85,8 +100,8 @@ size_t gtop_record_count(const GtopGrid &g) { return (size_t)(g.nx + 1) * (g.ny 
 // of its voxels — voxel x sits in records cx = x and x + 1 (and, clamped, in the border records beyond the grid's
 // first / last voxel), likewise y; level z in cz = z + 1 (and in the padding levels at the z ends).
 template <typename S, typename D>
-hipError_t gtop_launch_build_records(const GtopGrid &g, const S *field, D *rec, const int *vlo, const int *vhi,
-                                     hipStream_t stream) {
+hipError_t gtop_launch_build_records(const GtopGrid &g, const S *field, D *rec, float *rec32, const int *vlo,
+                                     const int *vhi, hipStream_t stream) {
   const int n[3] = {g.nx, g.ny, g.nz};
   int lo[3], hi[3];
   for (int k = 0; k < 3; ++k) {
@@ -99,12 +114,12 @@ hipError_t gtop_launch_build_records(const GtopGrid &g, const S *field, D *rec, 
       hi[k] = b >= n[k] - 1 ? n[k] + 1 : b + 1;
     }
   }
-  return launch_records<S, D>(g, field, rec, lo, hi, stream);
+  return launch_records<S, D>(g, field, rec, rec32, lo, hi, stream);
 }
 
-template hipError_t gtop_launch_build_records<double, double>(const GtopGrid &, const double *, double *, const int *,
-                                                              const int *, hipStream_t);
-template hipError_t gtop_launch_build_records<double, float>(const GtopGrid &, const double *, float *, const int *,
-                                                             const int *, hipStream_t);
-template hipError_t gtop_launch_build_records<float, float>(const GtopGrid &, const float *, float *, const int *,
-                                                            const int *, hipStream_t);
+template hipError_t gtop_launch_build_records<double, double>(const GtopGrid &, const double *, double *, float *,
+                                                              const int *, const int *, hipStream_t);
+template hipError_t gtop_launch_build_records<double, float>(const GtopGrid &, const double *, float *, float *,
+                                                             const int *, const int *, hipStream_t);
+template hipError_t gtop_launch_build_records<float, float>(const GtopGrid &, const float *, float *, float *,
+                                                            const int *, const int *, hipStream_t);
