@@ -244,6 +244,9 @@ void fill_args(const gtop_ctx *c, GtopKernelArgs<R> &a) {
   }
   a.res = (R)g.res;
   a.res_inv = (R)g.res_inv;
+  for (int i = 0; i < 3; ++i) a.idx_origin[i] = g.origin[i];
+  a.idx_half = 0.5 * g.res;
+  a.idx_rinv = g.res_inv;
   const gtop_params &p = c->prm;
   a.ws = (R)p.ws; a.wc = (R)p.wc; a.alpha = (R)p.alpha; a.d0 = (R)p.d0;
   a.inv_r = (R)1 / (R)p.r;

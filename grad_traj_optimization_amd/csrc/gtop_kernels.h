@@ -28,6 +28,9 @@ struct GtopKernelArgs {
   R lo[3], hi[3];   // min_range + 1e-4, max_range - 1e-4  (isInMap, sdf_map.cpp:55-69)
   float lo_f[3], hi_f[3];   // lo rounded up / hi rounded down to float: for a float p, p < lo <=> p < lo_f, p > hi <=> p > hi_f
   R res, res_inv;
+  // posToIndex's constants in double whatever R is: the fp32 kernels decide which cell a sample reads as the reference
+  // does, in double on the widened float position (gtop_kernels.hip IndexBox); the fp64 kernels do not read these
+  double idx_origin[3], idx_half, idx_rinv;
   // parameters — grad_traj_optimizer.cpp:5-32
   R ws, wc, alpha, d0, alpha_v, r_v, v0, alpha_a, r_a, a0;
   R inv_r, alpha_over_r;   // 1/r, alpha/r  (:509, :514)

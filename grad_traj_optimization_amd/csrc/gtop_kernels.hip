@@ -192,7 +192,6 @@ __device__ __forceinline__ double speed_sqrt(double s) {
 __device__ __forceinline__ float speed_sqrt(float s) { return sqrtf(s); }
 template <typename R> __device__ __forceinline__ R gfloor(R v);
 template <> __device__ __forceinline__ double gfloor<double>(double v) { return floor(v); }
-template <> __device__ __forceinline__ float gfloor<float>(float v) { return floorf(v); }
 template <typename R> __device__ __forceinline__ R gabs(R v);
 template <> __device__ __forceinline__ double gabs<double>(double v) { return fabs(v); }
 template <> __device__ __forceinline__ float gabs<float>(float v) { return fabsf(v); }
@@ -294,27 +293,34 @@ __device__ __forceinline__ bool out_of_map(const R (&lo)[3], const R (&hi)[3], R
 }
 
 
-// isInMap's box (sdf_map.cpp:55-69, margins included) and posToIndex's constants
+// isInMap's box (sdf_map.cpp:55-69, margins included)
 template <typename R> struct MapBox {
   R lo[3], hi[3];
-  R org[3], half, rinv;   // origin, res/2, 1/res of posToIndex (sdf_map.cpp:71-74, :201-204)
+};
+// posToIndex's constants (sdf_map.cpp:71-74, :201-204): origin, res/2, 1/res — in DOUBLE whatever the kernel's
+// arithmetic type.  Which cell a sample reads is decided as the reference decides it: the position, a `float` value
+// (:457-465), widened, and floor((pos - res/2 - origin) / res) in double.  The interpolant is continuous across cell
+// faces, its gradient is not, so a cell chosen in fp32 arithmetic (round 3's fp32 bodies) gave a sample within fp32's
+// rounding of a face — one in 1e5 — the neighbouring cell's gradient: a row's gradient off by that sample's weight.
+struct IndexBox {
+  double org[3], half, rinv;
 };
 
 template <typename R, bool WIDE>
-__device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, const MapBox<R> &box, R px, R py, R pz) {
+__device__ __forceinline__ SdfTap<R> sdf_issue(const GtopKernelArgs<R> &a, const IndexBox &box, double px, double py, double pz) {
   SdfTap<R> tp;
-  const R rinv = box.rinv, half = box.half;
+  const double rinv = box.rinv, half = box.half;
   // posToIndex(pos - 0.5 res)  (:201-204 -> :71-74)
-  const R tx = (px - half) - box.org[0], ty = (py - half) - box.org[1], tz = (pz - half) - box.org[2];
-  const R ux = tx * rinv, uy = ty * rinv, uz = tz * rinv;
-  const R fx = gfloor(ux), fy = gfloor(uy), fz = gfloor(uz);
+  const double tx = (px - half) - box.org[0], ty = (py - half) - box.org[1], tz = (pz - half) - box.org[2];
+  const double ux = tx * rinv, uy = ty * rinv, uz = tz * rinv;
+  const double fx = floor(ux), fy = floor(uy), fz = floor(uz);
   record_loads<R, WIDE>(a, (int)fx, (int)fy, (int)fz, tp.v);
   // indexToPos (:76-78) and diff (:209): (pos - centre(idx)) / res is the fractional
   // part of u (equal up to a few ulp of u, ~1e-14 of a voxel).  Written as the fused form the compiler
   // contracts `u - floor(u)` to where it can: every body, however it is scheduled, takes the same bits.
-  tp.dx = gfma(tx, rinv, -fx);
-  tp.dy = gfma(ty, rinv, -fy);
-  tp.dz = gfma(tz, rinv, -fz);
+  tp.dx = (R)fma(tx, rinv, -fx);
+  tp.dy = (R)fma(ty, rinv, -fy);
+  tp.dz = (R)fma(tz, rinv, -fz);
   return tp;
 }
 
@@ -341,7 +347,7 @@ __device__ __forceinline__ void gtop_wait_pairs(gtop_d2 (&raw)[4], double after0
                : "v"(after0), "v"(after1), "n"(LEFT));
 }
 
-__device__ __forceinline__ SdfTap<double> sdf_issue_asm(const GtopKernelArgs<double> &a, const MapBox<double> &box,
+__device__ __forceinline__ SdfTap<double> sdf_issue_asm(const GtopKernelArgs<double> &a, const IndexBox &box,
                                                         double px, double py, double pz, gtop_d2 (&raw)[4]) {
   typedef double R;
   SdfTap<R> tp;
@@ -411,26 +417,27 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// two SDFMap::getDistWithGradTrilinear queries (src/sdf_map.cpp:185-242)
+// two SDFMap::getDistWithGradTrilinear queries (src/sdf_map.cpp:185-242) at the positions pA, pB (`float` values, as
+// the reference holds them); the cell and the weights from double arithmetic on the widened position (IndexBox)
 template <bool WIDE>
-__device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 px, f2 py, f2 pz,
-                                             f2 &gx, f2 &gy, f2 &gz) {
-  const f2 res = splat(a.res), rinv = splat(a.res_inv), half = splat(0.5f * a.res);
-  const f2 ox = splat(a.origin[0]), oy = splat(a.origin[1]), oz = splat(a.origin[2]);
-  f2 fx = ((px - half) - ox) * rinv, fy = ((py - half) - oy) * rinv, fz = ((pz - half) - oz) * rinv;
-  fx = (f2){floorf(fx.x), floorf(fx.y)};
-  fy = (f2){floorf(fy.x), floorf(fy.y)};
-  fz = (f2){floorf(fz.x), floorf(fz.y)};
-  const f2 h = splat(0.5f);
-  const f2 dx = (px - ((fx + h) * res + ox)) * rinv;
-  const f2 dy = (py - ((fy + h) * res + oy)) * rinv;
-  const f2 dz = (pz - ((fz + h) * res + oz)) * rinv;
-
+__device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, const IndexBox &box, const float (&pA)[3],
+                                             const float (&pB)[3], f2 &gx, f2 &gy, f2 &gz) {
+  int idx[2][3];
+  float w[2][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double t = ((double)(c ? pB[k] : pA[k]) - box.half) - box.org[k];   // posToIndex(pos - 0.5 res), :201-204
+      const double f = floor(t * box.rinv);
+      idx[c][k] = (int)f;
+      w[c][k] = (float)fma(t, box.rinv, -f);                                     // diff, :206-209
+    }
+  const f2 dx = {w[0][0], w[1][0]}, dy = {w[0][1], w[1][1]}, dz = {w[0][2], w[1][2]};
   // the two records of each sample (record_loads): border clamps are in the records, dz is the plain fraction
   float c8[2][8];
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
-    record_loads<float, WIDE>(a, (int)(c ? fx.y : fx.x), (int)(c ? fy.y : fy.x), (int)(c ? fz.y : fz.x), c8[c]);
+  for (int c = 0; c < 2; ++c) record_loads<float, WIDE>(a, idx[c][0], idx[c][1], idx[c][2], c8[c]);
   const f2 v000 = {c8[0][0], c8[1][0]}, v010 = {c8[0][1], c8[1][1]};
   const f2 v100 = {c8[0][2], c8[1][2]}, v110 = {c8[0][3], c8[1][3]};
   const f2 v001 = {c8[0][4], c8[1][4]}, v011 = {c8[0][5], c8[1][5]};
@@ -450,19 +457,34 @@ __device__ __forceinline__ f2 sdf_query_pair(const GtopKernelArgs<float> &a, f2 
   return dist;
 }
 
-// Two samples (t.x, t.y) of one segment: everything phase 2 does per sample
+// Two samples (tA, tB) of one segment: everything phase 2 does per sample
 // (src/grad_traj_optimizer.cpp:353-381), accumulated component-wise into
 // acc2[19]; the caller adds the two components after its loop.
+// The POSITIONS are evaluated as the reference evaluates them — the polynomial in double (qd: the coefficients in
+// double; the sample times in double), rounded to `float` (:457-465) — and the cell they fall in is found in double
+// (sdf_query_pair), so the fp32 path reads the same cells and decides out-of-map the same way as the fp64 path and
+// the reference on the same inputs.  Everything else — velocity, blend, penalty, accumulation — is packed fp32.
 template <bool DYN, bool WIDE>
-__device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, const float *cq, f2 t,
-                                                bool liveA, bool liveB, float wdt, float dt, f2 (&acc2)[kRedVals]) {
+__device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, const IndexBox &box, const double (&qd)[3][6],
+                                                const float *cq, double tA, double tB, bool liveA, bool liveB, float wdt,
+                                                float dt, f2 (&acc2)[kRedVals]) {
+  float pA[3], pB[3];
+  {
+    const double a2 = tA * tA, a3 = a2 * tA, a4 = a2 * a2, a5 = a4 * tA;
+    const double b2 = tB * tB, b3 = b2 * tB, b4 = b2 * b2, b5 = b4 * tB;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pA[k] = (float)(qd[k][0] + qd[k][1] * tA + qd[k][2] * a2 + qd[k][3] * a3 + qd[k][4] * a4 + qd[k][5] * a5);
+      pB[k] = (float)(qd[k][0] + qd[k][1] * tB + qd[k][2] * b2 + qd[k][3] * b3 + qd[k][4] * b4 + qd[k][5] * b5);
+    }
+  }
+  const f2 t = {(float)tA, (float)tB};
   const f2 t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
   const f2 d2 = splat(2.0f) * t, d3 = splat(3.0f) * t2, d4 = splat(4.0f) * t3, d5 = splat(5.0f) * t4;   // d/dt of the powers
-  f2 pos[3], vel[3], acc3[3];
+  f2 vel[3], acc3[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float *q = cq + 6 * k;
-    pos[k] = splat(q[0]) + splat(q[1]) * t + splat(q[2]) * t2 + splat(q[3]) * t3 + splat(q[4]) * t4 + splat(q[5]) * t5;
     vel[k] = splat(q[1]) + splat(q[2]) * d2 + splat(q[3]) * d3 + splat(q[4]) * d4 + splat(q[5]) * d5;
     if (DYN) acc3[k] = splat(2.0f * q[2]) + splat(6.0f * q[3]) * t + splat(12.0f * q[4]) * t2 + splat(20.0f * q[5]) * t3;
   }
@@ -470,11 +492,13 @@ __device__ __forceinline__ void sample_pair_f32(const GtopKernelArgs<float> &a, 
   const f2 vn = (f2){__builtin_amdgcn_sqrtf(v2.x), __builtin_amdgcn_sqrtf(v2.y)} + splat(1e-5f);   // :358
   const f2 ivn = {__builtin_amdgcn_rcpf(vn.x), __builtin_amdgcn_rcpf(vn.y)};
   f2 g3[3];
-  f2 dist = sdf_query_pair<WIDE>(a, pos[0], pos[1], pos[2], g3[0], g3[1], g3[2]);   // :363
-  // isInMap (sdf_map.cpp:55-69); out of the map: dist = -1, grad := 0 (sdf_map.cpp:187).  Straight-line
-  // selects: with three wavefronts per SIMD they are cheaper than a rarely taken branch (measured: 21.9 against 22.9 us)
-  const bool outA = out_of_map(a.lo, a.hi, pos[0].x, pos[1].x, pos[2].x);
-  const bool outB = out_of_map(a.lo, a.hi, pos[0].y, pos[1].y, pos[2].y);
+  f2 dist = sdf_query_pair<WIDE>(a, box, pA, pB, g3[0], g3[1], g3[2]);   // :363
+  // isInMap (sdf_map.cpp:55-69) on the float position, against the bounds rounded INTO the box (lo_f / hi_f: for a float
+  // p, p < lo <=> p < lo_f — the reference's double comparison, decided exactly); out of the map: dist = -1, grad := 0
+  // (sdf_map.cpp:187).  Straight-line selects: with three wavefronts per SIMD they are cheaper than a
+  // rarely taken branch (measured: 21.9 against 22.9 us)
+  const bool outA = out_of_map(a.lo_f, a.hi_f, pA[0], pA[1], pA[2]);
+  const bool outB = out_of_map(a.lo_f, a.hi_f, pB[0], pB[1], pB[2]);
   if (outA) dist.x = -1.0f;
   if (outB) dist.y = -1.0f;
   const f2 arg = (splat(a.d0) - dist) * splat(a.inv_r);
@@ -577,6 +601,55 @@ struct GtopWaveConsts {
   R eps = 1e-5;                                                           // :358
 };
 
+// The fp32 kernels form the per-lane SET-UP — the 18 polynomial coefficients and the jerk term — in double (scalar fp32
+// and fp64 cost a SIMD the same four cycles per wave64 instruction; only PACKED fp32 is cheaper, and the set-up is
+// not packed): the coefficients are what the sample positions are evaluated from, which the reference does in double,
+// and the jerk term's 1/T^5 was where the fp32 path's arithmetic error sat.  Its constants, in double:
+template <typename R> struct GtopSetupConsts {};                                  // (fp64 kernels: K itself)
+template <> struct GtopSetupConsts<float> : GtopWaveConsts<double> {};
+__device__ __forceinline__ const GtopWaveConsts<double> &gtop_setup_consts(const GtopWaveConsts<double> &K, const GtopSetupConsts<double> &) { return K; }
+__device__ __forceinline__ const GtopWaveConsts<double> &gtop_setup_consts(const GtopWaveConsts<float> &, const GtopSetupConsts<float> &KD) { return KD; }
+
+// c = A_s^-1 d for the three axes (closed form; rows of A_s: src/qp_generator.cpp:185-195)
+template <typename C, typename R>
+__device__ __forceinline__ void gtop_form_coefficients(C (&q)[3][6], C T, const GtopWaveConsts<C> &K, const R (&w0)[3][3],
+                                                       const R (&w1)[3][3]) {
+  const C T2 = T * T;
+  const C iT = fast_rcp(T), iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const C p0 = (C)w0[k][0], v0 = (C)w0[k][1], a0 = (C)w0[k][2];
+    const C pT = (C)w1[k][0], vT = (C)w1[k][1], aT = (C)w1[k][2];
+    const C P = pT - p0 - v0 * T - (C)0.5 * a0 * T2;
+    const C V = (vT - v0 - a0 * T) * T;
+    const C A = (aT - a0) * T2;
+    q[k][0] = p0; q[k][1] = v0; q[k][2] = (C)0.5 * a0;
+    q[k][3] = (K.k10 * P - (C)4 * V + (C)0.5 * A) * iT3;
+    q[k][4] = (K.k7 * V - K.k15 * P - A) * iT4;
+    q[k][5] = (K.k6 * P - K.k3 * V + (C)0.5 * A) * iT5;
+  }
+}
+
+// The jerk term of one segment (Jerk Hessian Q_s: src/qp_generator.cpp:226-234, i,j in {3,4,5}): g[k][i-3] = wj 2 (Qc)_i,
+// the share of ws*(2Rfp'df + 2Rpp dp) (:330-336) in coefficient space, and cost = wj c'Qc, the share of d'Rd (:326-327)
+template <typename C>
+__device__ __forceinline__ C gtop_jerk_term(const C (&q)[3][6], C T, C wj, const GtopWaveConsts<C> &K, C (&g)[3][3]) {
+  const C T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+  const C Q33 = K.q36 * T, Q34 = K.q72 * T2, Q35 = K.q120 * T3, Q44 = K.q192 * T3, Q45 = K.q360 * T4, Q55 = K.q720 * T5;
+  const C wj2 = wj + wj;
+  C jc = (C)0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const C c3 = q[k][3], c4 = q[k][4], c5 = q[k][5];
+    const C q3 = Q33 * c3 + Q34 * c4 + Q35 * c5;
+    const C q4 = Q34 * c3 + Q44 * c4 + Q45 * c5;
+    const C q5 = Q35 * c3 + Q45 * c4 + Q55 * c5;
+    jc += c3 * q3 + c4 * q4 + c5 * q5;
+    g[k][0] = wj2 * q3; g[k][1] = wj2 * q4; g[k][2] = wj2 * q5;
+  }
+  return wj * jc;
+}
+
 // MINW = wavefronts per SIMD the register budget must leave room for: 2 in the latency regime (constants pinned
 // in VGPRs, 232 of them), 3 for batches that can fill a third (no pins; 168-VGPR budget).
 // MM = GtopMmaState (fp64, NT = 1): the batched CCSA-MMA driver's loop around the evaluation, all st.iters
@@ -598,8 +671,10 @@ struct GtopNoMma {};
 // (the same for the fp64 body that walks more than 12 segments in chunks: 19 spilled registers at 168)
 template <typename R, bool WIDE, typename MM, int SPL, int MINW, bool DYN, bool LONG>
 constexpr int gtop_wave_budget() {
-  return ((!std::is_same<MM, GtopNoMma>::value && SPL == 6) || DYN || ((WIDE || LONG) && sizeof(R) == 8 && SPL == 6)) ? 2
-                                                                                                                     : MINW;
+  return ((!std::is_same<MM, GtopNoMma>::value && SPL == 6) || DYN || ((WIDE || LONG) && sizeof(R) == 8 && SPL == 6) ||
+          (sizeof(R) == 4 && SPL == 6))   // (packed fp32 with the double coefficients of its exact positions: 190 VGPRs)
+             ? 2
+             : MINW;
 }
 
 // NW = 2: ONE trajectory of 7 .. 12 segments over TWO wavefronts at ten lanes per segment (a 128-thread workgroup;
@@ -611,7 +686,8 @@ template <typename R, bool WIDE, int SPL, int NT, bool COLLI, int MINW, typename
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(gtop_wave_budget<R, WIDE, MM, SPL, MINW, DYN, LONG>())))
 gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df, const R *__restrict__ arg_T,
                       const R *__restrict__ arg_sdf, int arg_B, int arg_m, int arg_t_stride, int arg_nx, int arg_ny,
-                      int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K, const MM st) {
+                      int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K, const MM st,
+                      const GtopSetupConsts<R> KD) {
   constexpr bool MMA = !std::is_same<MM, GtopNoMma>::value;
   static_assert(!MMA || NT == 1, "the optimizer loop: one trajectory per wavefront");
   // the optimizer's state, bounds, Df and T are fp64 whatever R is: with R = float only the evaluation runs in fp32
@@ -813,8 +889,11 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   const R wc = a.wc;
   ExpConsts expk;
   R pen_d0 = a.d0, pen_inv_r = a.inv_r, pen_alpha = a.alpha, pen_gd = -a.alpha_over_r;   // (:507-515)
-  MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]},
-                      {a.origin[0], a.origin[1], a.origin[2]}, (R)0.5 * a.res, a.res_inv};
+  MapBox<R> mapbox = {{a.lo[0], a.lo[1], a.lo[2]}, {a.hi[0], a.hi[1], a.hi[2]}};
+  // the cell lookup's constants, in double (fp32 kernels: the grid's own doubles, not their fp32 roundings)
+  IndexBox ibox;
+  if constexpr (kIsF32<R>) ibox = IndexBox{{a.idx_origin[0], a.idx_origin[1], a.idx_origin[2]}, a.idx_half, a.idx_rinv};
+  else ibox = IndexBox{{(double)a.origin[0], (double)a.origin[1], (double)a.origin[2]}, 0.5 * (double)a.res, (double)a.res_inv};
   if constexpr (COLLI && !kIsF32<R> && MINW <= 2 && !MMA) {   // (the optimizer loop has no registers to spare)
     // the exp constants only: with the map box pinned as well (12 more VGPRs) the body spills two registers since
     // the hand-issued loads hold all 12 corner pairs at once — 4.45 against 4.23 us
@@ -826,47 +905,48 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   GTOP_STAMP(3);   // inputs landed
 #endif
   // ---- coefficients c = A_s^-1 d (closed form; rows of A_s: src/qp_generator.cpp:185-195) ----
-  const R T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+  const R T2 = T * T;   // (for the A_s^-T at the end; the coefficients and the jerk term form their own powers)
   const R iT = fast_rcp(T), iT3 = iT * iT * iT, iT4 = iT3 * iT, iT5 = iT4 * iT;
   // :351, dt = T/30.  The quotient proper (a dozen instructions) is only needed where the sample COUNT hangs on
   // the accumulated sample time (tiny T, below); everywhere else T * (1/30) is the same to an ulp.
   const R dt = T * (R)(1.0 / 30.0);
   const R wdt = wc * dt;
   R q[3][6];
+  [[maybe_unused]] double qd[kIsF32<R> ? 3 : 1][6];   // fp32 kernels: the coefficients in double (positions; the jerk term)
+  const GtopWaveConsts<double> &KC = gtop_setup_consts(K, KD);
+  if constexpr (kIsF32<R>) {
+    gtop_form_coefficients(qd, (double)T, KC, w0, w1);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const R p0 = w0[k][0], v0 = w0[k][1], a0 = w0[k][2];
-    const R pT = w1[k][0], vT = w1[k][1], aT = w1[k][2];
-    const R P = pT - p0 - v0 * T - (R)0.5 * a0 * T2;
-    const R V = (vT - v0 - a0 * T) * T;
-    const R A = (aT - a0) * T2;
-    q[k][0] = p0; q[k][1] = v0; q[k][2] = (R)0.5 * a0;
-    q[k][3] = (K.k10 * P - (R)4 * V + (R)0.5 * A) * iT3;
-    q[k][4] = (K.k7 * V - K.k15 * P - A) * iT4;
-    q[k][5] = (K.k6 * P - K.k3 * V + (R)0.5 * A) * iT5;
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) q[k][c] = (R)qd[k][c];
+  } else {
+    gtop_form_coefficients(q, T, K, w0, w1);
   }
   // The jerk term, as the START value of the accumulators (a lambda: it is placed where the distance-field
   // loads are in flight, see below).  Jerk Hessian Q_s: src/qp_generator.cpp:226-234, i,j in {3,4,5}.
   R acc[kRedVals];
   auto jerk_init = [&]() {
-    const R Q33 = K.q36 * T, Q34 = K.q72 * T2, Q35 = K.q120 * T3, Q44 = K.q192 * T3, Q45 = K.q360 * T4,
-            Q55 = K.q720 * T5;
     // lane 0 of a segment carries the segment's jerk term into the sums
     const R wj = (seg_ok & (li == 0)) ? ws : (R)0;
-    const R wj2 = wj + wj;
-    R jc = (R)0;
+    R g[3][3], jcost;
+    if constexpr (kIsF32<R>) {   // in double, from the double coefficients (see GtopSetupConsts)
+      double gdd[3][3];
+      jcost = (R)gtop_jerk_term(qd, (double)T, (double)wj, KC, gdd);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[k][i] = (R)gdd[k][i];
+    } else {
+      jcost = gtop_jerk_term(q, T, wj, K, g);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const R c3 = q[k][3], c4 = q[k][4], c5 = q[k][5];
-      const R q3 = Q33 * c3 + Q34 * c4 + Q35 * c5;
-      const R q4 = Q34 * c3 + Q44 * c4 + Q45 * c5;
-      const R q5 = Q35 * c3 + Q45 * c4 + Q55 * c5;
-      jc += c3 * q3 + c4 * q4 + c5 * q5;   // c'Qc: this (s,k)'s share of d'Rd (:326-327)
-      // ws * 2Qc: share of ws*(2Rfp'df + 2Rpp dp) (:330-336) in coefficient space (entries 0..2 are zero)
+      // (entries 0..2 of the coefficient-space gradient are zero)
       acc[6 * k + 0] = (R)0; acc[6 * k + 1] = (R)0; acc[6 * k + 2] = (R)0;
-      acc[6 * k + 3] = wj2 * q3; acc[6 * k + 4] = wj2 * q4; acc[6 * k + 5] = wj2 * q5;
+      acc[6 * k + 3] = g[k][0]; acc[6 * k + 4] = g[k][1]; acc[6 * k + 5] = g[k][2];
     }
-    acc[18] = wj * jc;
+    acc[18] = jcost;
   };
 
   // ---- collision samples (:345-409); sample index = li + j*LPS ----
@@ -876,55 +956,63 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // Every term of a sample carries the factor alpha * wc * dt (cd of :509 times the weights of :373/:417);
     // a sample past the loop bound of :353 contributes nothing, i.e. has that factor zero.  With T >= 0.0301
     // all 30 samples are inside the bound, so only the replay path ever has to clear it.
+    // Sample TIMES are formed in double whatever R is (the reference's are doubles, and the fp32 kernels evaluate the
+    // positions from them in double: see sample_pair_f32); R = double: TT is R, nothing changes.
+    using TT = double;
+    const TT Tt = (TT)T;
+    TT dtt;
+    if constexpr (kIsF32<R>) dtt = Tt * (1.0 / 30.0);
+    else dtt = (TT)dt;
     const bool tiny_T = T < (R)0.0301;
     const bool any_tiny = __ballot(tiny_T) != 0ull;   // wave-uniform, rare
     // The quotient proper (:351) is only needed on that replay path; the empty asm keeps the dozen instructions of
     // the division inside the rare branch (the compiler otherwise computes it up front for everybody).
     auto tiny_dt = [&]() {
-      R Tq = T;
+      TT Tq = Tt;
       asm volatile("" : "+v"(Tq));
-      return Tq / (R)30.0;
+      return Tq / (TT)30.0;
     };
     const R aw_all = pen_alpha * wdt;
     // (sdt: the sample's own dt, zero past the loop bound — the factor every DYN term carries; unused otherwise)
-    auto sample_time = [&](int j, R &t, R &awj, R &sdt) {
-      t = (R)(li + j * LPS) * dt + (R)1e-3;
+    auto sample_time = [&](int j, TT &t, R &awj, R &sdt) {
+      t = (TT)(li + j * LPS) * dtt + (TT)1e-3;
       awj = aw_all;
       sdt = dt;
       if (any_tiny) {
         if (tiny_T) {
-          const R dtq = tiny_dt();
-          t = (R)1e-3;
+          const TT dtq = tiny_dt();
+          t = (TT)1e-3;
           for (int i = 0; i < li + j * LPS; ++i) t += dtq;
-          awj = (t < T) ? pen_alpha * (wc * dtq) : (R)0;
-          sdt = (t < T) ? dtq : (R)0;
+          awj = (t < Tt) ? pen_alpha * (wc * (R)dtq) : (R)0;
+          sdt = (t < Tt) ? (R)dtq : (R)0;
           // a sample past the loop bound (:353) is not evaluated by the reference; here it is, with weight 0 — at the
           // first sample's time rather than on the extrapolated polynomial, where an exp could overflow into 0 * inf
-          t = (t < T) ? t : (R)1e-3;
+          t = (t < Tt) ? t : (TT)1e-3;
         }
       }
     };
     constexpr int NTS = (MINW <= 2) ? SPL : 1;   // latency regime: all sample times before the first load
-    R ts[NTS], aw[NTS];
+    TT ts[NTS];
+    R aw[NTS];
     [[maybe_unused]] R sdts[NTS];
     if constexpr (MINW <= 2) {
 #pragma unroll
       for (int j = 0; j < SPL; ++j) {
-        ts[j] = (R)(li + j * LPS) * dt + (R)1e-3;
+        ts[j] = (TT)(li + j * LPS) * dtt + (TT)1e-3;
         aw[j] = aw_all;
         sdts[j] = dt;
       }
       if (any_tiny) {   // ONE wave-uniform branch for all of the lane's samples: the addition chain runs on from one to the next
         if (tiny_T) {
-          const R dtq = tiny_dt();
-          R t = (R)1e-3;
+          const TT dtq = tiny_dt();
+          TT t = (TT)1e-3;
           int i = 0;
 #pragma unroll
           for (int j = 0; j < SPL; ++j) {
             for (; i < li + j * LPS; ++i) t += dtq;
-            ts[j] = (t < T) ? t : (R)1e-3;   // (past the loop bound: weight 0, evaluated at the first sample's time; see sample_time)
-            aw[j] = (t < T) ? pen_alpha * (wc * dtq) : (R)0;
-            sdts[j] = (t < T) ? dtq : (R)0;
+            ts[j] = (t < Tt) ? t : (TT)1e-3;   // (past the loop bound: weight 0, evaluated at the first sample's time; see sample_time)
+            aw[j] = (t < Tt) ? pen_alpha * (wc * (R)dtq) : (R)0;
+            sdts[j] = (t < Tt) ? (R)dtq : (R)0;
           }
         }
       }
@@ -953,11 +1041,12 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       for (int v = 0; v < kRedVals; ++v) acc2[v] = (f2){(float)acc[v], 0.0f};
 #pragma unroll 1
       for (int jj = 0; jj < SPL; jj += 2) {
-        R tA, tB, awA, awB, sdA, sdB;
+        TT tA, tB;
+        R awA, awB, sdA, sdB;
         sample_time(jj, tA, awA, sdA);
         sample_time(jj + 1, tB, awB, sdB);
         // (live = inside the loop bound of :353; without DYN every term carries alpha, so alpha*wc*dt != 0 says the same)
-        sample_pair_f32<DYN, WIDE>(reinterpret_cast<const GtopKernelArgs<float> &>(a), cq, (f2){(float)tA, (float)tB},
+        sample_pair_f32<DYN, WIDE>(reinterpret_cast<const GtopKernelArgs<float> &>(a), ibox, qd, cq, tA, tB,
                                    DYN ? sdA != (R)0 : awA != (R)0, DYN ? sdB != (R)0 : awB != (R)0, (float)wdt,
                                    (float)dt, acc2);
       }
@@ -983,20 +1072,28 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       constexpr bool kRareOut = CH == SPL;
       [[maybe_unused]] float pmin[3], pmax[3];
       [[maybe_unused]] bool outs[CH];
-      auto position = [&](int k, R t, R t2, R t3, R t4, R t5) {
-        return (float)(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
+      // (the position polynomial in double — fp32 kernels: from the double coefficients and the double sample time)
+      auto position = [&](int k, TT t, TT t2, TT t3, TT t4, TT t5) {
+        if constexpr (kIsF32<R>)
+          return (float)(qd[k][0] + qd[k][1] * t + qd[k][2] * t2 + qd[k][3] * t3 + qd[k][4] * t4 + qd[k][5] * t5);
+        else
+          return (float)(q[k][0] + q[k][1] * t + q[k][2] * t2 + q[k][3] * t3 + q[k][4] * t4 + q[k][5] * t5);
       };
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        const R t = ts[MINW <= 2 ? j0 + c : 0];
-        const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+        const TT tt = ts[MINW <= 2 ? j0 + c : 0];
+        const TT u2 = tt * tt, u3 = u2 * tt, u4 = u2 * u2, u5 = u4 * tt;
+        const R t = (R)tt;
+        const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2;   // (R = double: the same values as u2 .. u4)
         const R d2 = (R)2 * t, d3 = K.k3 * t2, d4 = (R)4 * t3, d5 = K.k5 * t4;   // d/dt of the powers
-        R pos[3];
+        double pos[3];
+        [[maybe_unused]] float posf[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           // :457-465 / :477-485 (sums in the reference's order), then the float round trip
-          const float pf = position(k, t, t2, t3, t4, t5);
-          pos[k] = (R)pf;
+          const float pf = position(k, tt, u2, u3, u4, u5);
+          pos[k] = (double)pf;
+          posf[k] = pf;
           if constexpr (kRareOut) {
             pmin[k] = c == 0 ? pf : fminf(pmin[k], pf);
             pmax[k] = c == 0 ? pf : fmaxf(pmax[k], pf);
@@ -1005,9 +1102,12 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
           if constexpr (DYN)   // getAccelerationFromCoeff, :491-505 (through `float` like the other two)
             accs[c][k] = round_through_float((R)2 * q[k][2] + K.k6 * q[k][3] * t + (R)12 * q[k][4] * t2 + (R)20 * q[k][5] * t3);
         }
-        if constexpr (ASMLD) taps[c] = sdf_issue_asm(a, mapbox, pos[0], pos[1], pos[2], raw[c]);
-        else taps[c] = sdf_issue<R, WIDE>(a, mapbox, pos[0], pos[1], pos[2]);   // :363
-        if constexpr (!kRareOut) outs[c] = out_of_map(mapbox.lo, mapbox.hi, pos[0], pos[1], pos[2]);
+        if constexpr (ASMLD) taps[c] = sdf_issue_asm(a, ibox, pos[0], pos[1], pos[2], raw[c]);
+        else taps[c] = sdf_issue<R, WIDE>(a, ibox, pos[0], pos[1], pos[2]);   // :363
+        if constexpr (!kRareOut) {
+          if constexpr (kIsF32<R>) outs[c] = out_of_map(a.lo_f, a.hi_f, posf[0], posf[1], posf[2]);   // (exact: see above)
+          else outs[c] = out_of_map(mapbox.lo, mapbox.hi, (R)pos[0], (R)pos[1], (R)pos[2]);
+        }
       }
       bool any_out = false;
       if constexpr (kRareOut) {
@@ -1053,7 +1153,8 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
             taps[c].v[2 * q + 1] = raw[c][q].y;
           }
         }
-        const R t = ts[MINW <= 2 ? j0 + c : 0];
+        const TT tt = ts[MINW <= 2 ? j0 + c : 0];
+        const R t = (R)tt;
         const R *vel = vels[c];
         const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
         const R vn = vns[c], ivn = ivns[c];
@@ -1062,9 +1163,13 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         if constexpr (!kRareOut) {   // dist = -1 (sdf_map.cpp:187); grad := 0 below, through its weight f1
           dist = outs[c] ? (R)-1 : dist;
         } else if (any_out) {   // (rare) which of the samples it is: the reference's own test on the sample's position
-          const R px = (R)position(0, t, t2, t3, t4, t5), py = (R)position(1, t, t2, t3, t4, t5),
-                  pz = (R)position(2, t, t2, t3, t4, t5);
-          if (out_of_map(mapbox.lo, mapbox.hi, px, py, pz)) {   // dist = -1, grad := 0 (sdf_map.cpp:187)
+          const TT u2 = tt * tt, u3 = u2 * tt, u4 = u2 * u2, u5 = u4 * tt;
+          const float pfx = position(0, tt, u2, u3, u4, u5), pfy = position(1, tt, u2, u3, u4, u5),
+                      pfz = position(2, tt, u2, u3, u4, u5);
+          bool is_out;
+          if constexpr (kIsF32<R>) is_out = out_of_map(a.lo_f, a.hi_f, pfx, pfy, pfz);   // (exact: see stage A)
+          else is_out = out_of_map(mapbox.lo, mapbox.hi, (R)pfx, (R)pfy, (R)pfz);
+          if (is_out) {   // dist = -1, grad := 0 (sdf_map.cpp:187)
             dist = (R)-1;
             g3[0] = g3[1] = g3[2] = (R)0;
           }
@@ -1337,7 +1442,7 @@ namespace {
 
 template <typename R, typename MM>
 using WaveKernelFn = void (*)(const R *, const R *, const R *, const R *, int, int, int, int, int, int,
-                              const GtopKernelArgs<R>, const GtopWaveConsts<R>, const MM);
+                              const GtopKernelArgs<R>, const GtopWaveConsts<R>, const MM, const GtopSetupConsts<R>);
 
 // one geometry: the collision-free, the ordinary and the DYN instantiation (DYN: one sample at a time, MINW >= 3)
 template <typename R, bool WIDE, int SPL, int NT, int MINW, typename MM, bool LONG, int NW = 1>
@@ -1410,7 +1515,7 @@ static hipError_t launch_wave(const GtopKernelArgs<R> &args, const MM &st, const
     const int groups = (s.B + plan.nt - 1) / plan.nt;
     const int grid = 8 * ((groups + 7) / 8);   // the kernel deals its workgroups over 8 XCD-contiguous ranges
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * plan.nw), smem, stream, s.x, s.Df, s.T, s.sdf, s.B, s.m, s.t_stride, s.nx, s.ny,
-                       s.nz, s, GtopWaveConsts<R>{}, st);
+                       s.nz, s, GtopWaveConsts<R>{}, st, GtopSetupConsts<R>{});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
