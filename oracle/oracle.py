@@ -254,17 +254,7 @@ def optimize_batch(T, Df, x0, lb, ub, sdf, params, max_evals, nthreads=1):
     """bench.py's CPU leg beside the device optimizer (oracle/cpu_optimizer.cpp): per trajectory a serial CCSA-MMA
     (csrc/mma.hpp standing in for NLopt's LD_MMA, grad_traj_optimizer.cpp:137-195) around the oracle callback.
     Returns (x, min_cost, nevals, seconds)."""
-    global _opt_lib
-    if _opt_lib is None:
-        lib()
-        so = os.path.join(_HERE, "_build", "libgtop_cpu_optimizer.so")
-        subprocess.check_call(["make", "-C", _HERE, "-s", "_build/libgtop_cpu_optimizer.so"])
-        L = C.CDLL(so)
-        dp = C.POINTER(C.c_double)
-        L.oracle_optimize_batch.argtypes = [C.c_int, C.c_int, dp, C.c_int, dp, C.POINTER(OracleParams),
-                                            C.POINTER(OracleSdf), dp, dp, dp, C.c_int, dp, C.POINTER(C.c_int), C.c_int]
-        L.oracle_optimize_batch.restype = C.c_double
-        _opt_lib = L
+    _optimizer_lib()
     x = _f64(x0).copy()
     B, n = x.shape
     m = n // 9 + 1
@@ -279,6 +269,62 @@ def optimize_batch(T, Df, x0, lb, ub, sdf, params, max_evals, nthreads=1):
     if sec < 0:
         raise ValueError("oracle_optimize_batch failed")
     return x, cost, nev, sec
+
+
+def _optimizer_lib():
+    global _opt_lib
+    if _opt_lib is None:
+        lib()
+        so = os.path.join(_HERE, "_build", "libgtop_cpu_optimizer.so")
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_build/libgtop_cpu_optimizer.so"])
+        L = C.CDLL(so)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.oracle_optimize_batch.argtypes = [C.c_int, C.c_int, dp, C.c_int, dp, C.POINTER(OracleParams),
+                                            C.POINTER(OracleSdf), dp, dp, dp, C.c_int, dp, ip, C.c_int]
+        L.oracle_optimize_batch.restype = C.c_double
+        L.oracle_mma_trace.argtypes = [C.c_int, dp, dp, C.POINTER(OracleParams), C.POINTER(OracleSdf), dp, dp, dp, C.c_int,
+                                       C.c_double, C.c_double, dp, ip, dp, dp, C.c_int]
+        L.oracle_mma_trace.restype = C.c_int
+        L.oracle_mma_trace_quadratic.argtypes = [C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, ip, dp,
+                                                 dp, C.c_int]
+        L.oracle_mma_trace_quadratic.restype = C.c_int
+        _opt_lib = L
+    return _opt_lib
+
+
+def _trace_result(code, x, minf, nev, xs, fs):
+    k = int(nev.value)
+    return dict(x=x, minf=float(minf.value), nevals=k, code=int(code), xs=xs[:k].copy(), fs=fs[:k].copy())
+
+
+def mma_trace(T, Df, x0, lb, ub, sdf, params, max_evals, ftol_rel=0.0, xtol_rel=0.0):
+    """The product's host optimizer (csrc/mma.hpp) around the oracle callback for ONE trajectory, every evaluation
+    recorded (oracle/cpu_optimizer.cpp oracle_mma_trace): dict(x, minf, nevals, code, xs, fs)."""
+    L = _optimizer_lib()
+    x = _f64(x0).copy().reshape(-1)
+    n = x.size
+    m = n // 9 + 1
+    T, Df, lb, ub = _f64(T).reshape(m), _f64(Df).reshape(18), _f64(lb).reshape(n), _f64(ub).reshape(n)
+    xs, fs = np.zeros((max_evals + 1, n)), np.zeros(max_evals + 1)
+    minf, nev = C.c_double(), C.c_int()
+    code = L.oracle_mma_trace(m, _p(T), _p(Df), C.byref(params), C.byref(sdf.c), _p(x), _p(lb), _p(ub), int(max_evals),
+                              float(ftol_rel), float(xtol_rel), C.byref(minf), C.byref(nev), _p(xs), _p(fs), max_evals + 1)
+    if code == -2:
+        raise ValueError("oracle_mma_trace failed")
+    return _trace_result(code, x, minf, nev, xs, fs)
+
+
+def mma_trace_quadratic(a, c, x0, lb, ub, max_evals, ftol_rel=0.0, xtol_rel=0.0):
+    """The same on f(x) = sum a_j (x_j - c_j)^2 / 2 (known answers of tests/test_mma_twin.py)."""
+    L = _optimizer_lib()
+    x = _f64(x0).copy().reshape(-1)
+    n = x.size
+    a, c, lb, ub = (_f64(v).reshape(n) for v in (a, c, lb, ub))
+    xs, fs = np.zeros((max_evals + 1, n)), np.zeros(max_evals + 1)
+    minf, nev = C.c_double(), C.c_int()
+    code = L.oracle_mma_trace_quadratic(n, _p(a), _p(c), _p(x), _p(lb), _p(ub), int(max_evals), float(ftol_rel),
+                                        float(xtol_rel), C.byref(minf), C.byref(nev), _p(xs), _p(fs), max_evals + 1)
+    return _trace_result(code, x, minf, nev, xs, fs)
 
 
 def coefficients(T, Df, x, L=None):

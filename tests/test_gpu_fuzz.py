@@ -161,6 +161,44 @@ def test_random_draw_fp32(gtop, oracle_mod, seed):
     ctx.close()
 
 
+def _narrowest_margin(oracle_mod, mp, sdf, kw, T, Df, x0, lb, ub, evals):
+    """The serial road of one trajectory (oracle/mma_twin.py around the oracle callback) and the narrowest margin any of
+    its decisions had: relative |g - f| of an inner-loop test, relative |f - fbest| of an acceptance, or the distance
+    (in voxels) of a sample of a trial point to the nearest voxel-cell face."""
+    from oracle import mma_twin
+    prm = oracle_mod.make_params(**kw)
+    gen = oracle_mod.generator(T)
+    m = len(T)
+    best = {"margin": np.inf, "what": None, "eval": -1}
+    count = [0]
+
+    def note(v, what):
+        if v < best["margin"]:
+            best.update(margin=float(v), what=what, eval=count[0])
+
+    def faces(x):          # sample positions as the callback forms them (:353, :457-465): float, then posToIndex's u
+        coe = oracle_mod.coefficients(T, Df, x, L=gen["L"]).reshape(m, 3, 6)
+        for s in range(m):
+            dt, t = T[s] / 30.0, 1e-3
+            while t < T[s]:
+                p = np.array([sum(coe[s, k, j] * t ** j for j in range(6)) for k in range(3)], dtype=np.float32).astype(np.float64)
+                u = ((p - 0.5 * mp.resolution) - mp.origin) * (1.0 / mp.resolution)
+                note(float(np.min(np.abs(u - np.round(u)))), "sample on a cell face")
+                t += dt
+
+    def observe(xcur, fcur, g, fbest):
+        count[0] += 1
+        if np.isfinite(fcur) and np.isfinite(g):
+            note(abs(g - fcur) / max(abs(fcur), 1e-300), "inner-loop tie g ~ f")
+            note(abs(fcur - fbest) / max(abs(fbest), 1e-300), "acceptance tie f ~ fbest")
+        faces(xcur)
+
+    def f(x):
+        return oracle_mod.cost_grad(T, Df, x, sdf, prm, L=gen["L"], R=gen["R"])
+    mma_twin.minimize(f, x0, lb, ub, evals, observe=observe)
+    return best
+
+
 @pytest.mark.parametrize("seed", seeds(2000, 40))
 def test_random_draw_optimizer(gtop, oracle_mod, seed):
     """The batched device optimizer on random draws against the serial CCSA-MMA of csrc/mma.hpp driven by the oracle
@@ -192,12 +230,18 @@ def test_random_draw_optimizer(gtop, oracle_mod, seed):
     ctx.close()
     what = (seed, b.m, B, evals, kw)
     assert np.array_equal(nev[ok], n_ref[ok]), what
-    # Same iterates on (nearly) every row: a trial point with a sample within an ulp of a voxel-cell face or an
-    # accept / reject tie can send one trajectory down another road after a dozen evaluations (4 of 3 040 draws had one
-    # or two such rows of 24); every row still ends no worse than it started.
+    # Same road on EVERY row — or a named reason (round 4).  The device evaluates the callback to 1e-12 of the oracle,
+    # so the two loops can only part where a decision of the serial road hangs on less than that: an inner-loop test
+    # g >= f or an acceptance f < fbest that is a tie, or a trial point with a sample within 1e-9 of a voxel-cell face
+    # (the interpolant's gradient jumps there).  A row that differs is re-run through the independent numpy restatement
+    # of the algorithm (oracle/mma_twin.py) around the oracle callback, which reports its narrowest margin: the row is
+    # excused only if that is below 1e-9.  (4 of 3 040 draws had one or two such rows of 24; round 3 excused up to 10 %
+    # of the rows of every draw without asking why.)
     same = (np.abs(costs - c_ref) <= 1e-6 * np.abs(c_ref)) & \
            (np.max(np.abs(xs - x_ref), axis=1) <= 1e-6 * np.maximum(1.0, np.max(np.abs(x_ref), axis=1)))
-    assert same[ok].mean() >= 0.9, (what, float(same[ok].mean()))
+    for i in np.nonzero(ok & ~same)[0]:
+        why = _narrowest_margin(oracle_mod, mp, sdf, kw, T[i], Df[i], x0[i], lb[i], ub[i], evals)
+        assert why["margin"] < 1e-9, (what, int(i), why)
     c0 = oracle_mod.eval_batch(T, Df, np.clip(x0, lb, ub), sdf, oracle_mod.make_params(**kw), nthreads=8)[0]
     assert np.all(costs[ok] <= c0[ok] * (1 + 1e-9)), what
     assert np.all(xs >= lb - 1e-12) and np.all(xs <= ub + 1e-12)

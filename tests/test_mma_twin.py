@@ -1,0 +1,153 @@
+"""The optimizer around the callback against an oracle that is NOT the product's own code.
+
+Round 3's reference for the batched device optimizer was csrc/mma.hpp — product code — wrapped by
+oracle/cpu_optimizer.cpp.  Here: (1) oracle/mma_twin.py, a second restatement of NLopt 2.5.0's LD_MMA (Svanberg 2002)
+in numpy that shares no code with the product, reproduces every committed trace of tests/golden/mma_traces.npz
+(evaluation points, values, evaluation count, stop code) to 1e-12, and so does csrc/mma.hpp run now; (2) both reproduce
+HAND-DERIVED known answers on separable convex quadratics, where the first trial point is a rational number one can
+compute on paper and the minimiser over the box is clip(c, lb, ub).  What stays unpinned: NLopt's own iterates (NLopt
+cannot be run in this image)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mma_twin
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mma_traces.npz")
+CASES = ["m3_maxeval", "m6_maxeval", "m6_ftol", "m4_xtol", "m6_tight_box", "m8_both_tols", "m5_smooth_only"]
+TOL = 1e-12
+
+
+def _load(name, oracle_mod):
+    z = np.load(GOLD)
+    g = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+    grid = tuple(int(v) for v in g["grid"])
+    occ = np.unpackbits(g["occupancy"])[:int(np.prod(grid))].reshape(grid)
+    sdf = oracle_mod.Sdf.from_map_size(g["origin"], float(g["resolution"]), g["map_size"])
+    assert sdf.grid == grid
+    sdf.build_from_occupancy(occ)
+    over = {k: float(v) for k, v in zip(("ws", "wc"), g["params"]) if not np.isnan(v)}
+    return g, sdf, oracle_mod.make_params(**over)
+
+
+def _same(trace, g):
+    assert trace["nevals"] == int(g["nevals"]) and trace["code"] == int(g["code"])
+    assert np.max(np.abs(trace["xs"] - g["xs"]) / np.maximum(1.0, np.abs(g["xs"]))) <= TOL
+    assert np.max(np.abs(trace["fs"] - g["fs"]) / np.abs(g["fs"])) <= TOL
+    assert abs(trace["minf"] - float(g["minf"])) <= TOL * abs(float(g["minf"]))
+    assert np.max(np.abs(trace["x"] - g["x"]) / np.maximum(1.0, np.abs(g["x"]))) <= TOL
+
+
+def test_goldens_cover_every_stop_code():
+    z = np.load(GOLD)
+    assert sorted({int(z[f"{c}/code"]) for c in CASES}) == [3, 4, 5]       # FTOL, XTOL, MAXEVAL
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_independent_twin_reproduces_the_golden_trace(oracle_mod, name):
+    g, sdf, prm = _load(name, oracle_mod)
+    gen = oracle_mod.generator(g["T"])
+    maxeval, ftol, xtol = int(g["stop"][0]), float(g["stop"][1]), float(g["stop"][2])
+
+    def f(x):
+        return oracle_mod.cost_grad(g["T"], g["Df"], x, sdf, prm, L=gen["L"], R=gen["R"])
+    _same(mma_twin.minimize(f, g["x0"], g["lb"], g["ub"], maxeval, ftol, xtol), g)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_header_reproduces_the_golden_trace(oracle_mod, name):
+    g, sdf, prm = _load(name, oracle_mod)
+    maxeval, ftol, xtol = int(g["stop"][0]), float(g["stop"][1]), float(g["stop"][2])
+    _same(oracle_mod.mma_trace(g["T"], g["Df"], g["x0"], g["lb"], g["ub"], sdf, prm, maxeval, ftol, xtol), g)
+
+
+# ---- hand-derived known answers -------------------------------------------------------------------------------------
+# f(x) = sum_j a_j (x_j - c_j)^2 / 2, gradient a_j (x_j - c_j).  First outer iteration: rho = 1, sigma_j = (ub_j - lb_j)/2.
+# Per coordinate with d = a (x0 - c):  u = d sigma^2,  v = |d| sigma + 1/2,  r = u / (v sigma) = |d| sigma / (|d| sigma + 1/2),
+#   dx = (u/v) / (-1 - sqrt(1 - r^2)),  then the box and the 0.9 sigma move limit.
+# Choosing |d| sigma = 2 makes r = 4/5 and sqrt(1 - r^2) = 3/5 exactly:  dx = -sign(d) (4/5) sigma / (8/5) = -sign(d) sigma / 2.
+# Choosing |d| sigma = 3/4 makes r = 3/5, sqrt = 4/5:                   dx = -sign(d) (3/5) sigma / (9/5) = -sign(d) sigma / 3.
+
+def _both(a, c, x0, lb, ub, maxeval, ftol=0.0, xtol=0.0, oracle_mod=None):
+    a, c = np.asarray(a, float), np.asarray(c, float)
+
+    def f(x):          # (summed in index order, as the C objective of oracle_mma_trace_quadratic sums it: the same bits)
+        d = x - c
+        v = 0.0
+        for t in 0.5 * a * d * d:
+            v += float(t)
+        return v, a * d
+    return (mma_twin.minimize(f, x0, lb, ub, maxeval, ftol, xtol),
+            oracle_mod.mma_trace_quadratic(a, c, x0, lb, ub, maxeval, ftol, xtol))
+
+
+def test_known_answer_one_dimension(oracle_mod):
+    """f = (x + 1)^2 / 4 on [-1, 3] from x0 = 1: sigma = 2, d = f'(1) = 1, |d| sigma = 2  =>  dx = -sigma/2 = -1: the
+    first trial point is 0.  The approximant there: g(0) = f(x0) + (d sigma^2 dx + (|d| sigma + 1/2) dx^2) / (sigma^2 - dx^2)
+    = 1 + (-4 + 5/2) / 3 = 1/2 > f(0) = 1/4: conservative, so the inner loop ends at its first trial point and the
+    point is accepted.  The minimiser over the box is its lower bound, x = -1 = c."""
+    for tr in _both([0.5], [-1.0], [1.0], [-1.0], [3.0], 200, xtol=1e-12, oracle_mod=oracle_mod):
+        assert abs(tr["xs"][1][0]) <= 1e-15 and tr["fs"][0] == 1.0 and abs(tr["fs"][1] - 0.25) <= 1e-15
+        assert tr["fs"][2] < 0.25                        # the second outer iteration starts from the accepted point
+        assert tr["code"] in (mma_twin.XTOL_REACHED, mma_twin.FTOL_REACHED) and tr["nevals"] < 200
+        assert abs(tr["x"][0] + 1.0) <= 1e-9 and tr["minf"] <= 1e-18
+
+
+def test_known_answer_relstop_catches_new_equal_old(oracle_mod):
+    """Started AT the minimiser of x^2/2 (gradient 0): dx = 0, the trial point is the start point, g = f = 0 (inner
+    loop done), and |f - fprev| < ftol (|f| + |fprev|)/2 reads 0 < 0 — false; stop.c's `new == old` clause is what ends
+    the run: FTOL after exactly 2 evaluations."""
+    for tr in _both([1.0], [0.0], [0.0], [-1.0], [1.0], 50, ftol=1e-8, oracle_mod=oracle_mod):
+        assert tr["nevals"] == 2 and tr["code"] == mma_twin.FTOL_REACHED
+        assert np.all(tr["xs"] == 0.0) and np.all(tr["fs"] == 0.0)
+
+
+def test_known_answer_first_step_and_box_constrained_minimiser(oracle_mod):
+    """Four coordinates, a = 1, all from x0 = 1:
+       j = 0: box [0, 2]   (sigma 1),   c = -1    (d = 2,   |d| sigma = 2)   =>  dx = -1/2      -> 1/2
+       j = 1: box [0.25, 1.75] (sigma 3/4), c = 0 (d = 1,   |d| sigma = 3/4) =>  dx = -1/4      -> 3/4
+       j = 2: box [0.8, 2.8] (sigma 1), c = -1    (d = 2,   |d| sigma = 2)   =>  dx = -1/2, but the box stops it at 0.8
+       j = 3: box [0, 2]   (sigma 1),   c = 3     (d = -2,  |d| sigma = 2)   =>  dx = +1/2      -> 3/2
+    The minimiser over the box is clip(c, lb, ub) = (0, 0.25, 0.8, 2): coordinates 0, 1, 2 end on their lower bound,
+    coordinate 3 on its upper — three of four bounds active at the solution."""
+    a, c = [1.0] * 4, [-1.0, 0.0, -1.0, 3.0]
+    lb, ub = [0.0, 0.25, 0.8, 0.0], [2.0, 1.75, 2.8, 2.0]
+    for tr in _both(a, c, [1.0] * 4, lb, ub, 400, xtol=1e-10, oracle_mod=oracle_mod):
+        assert np.allclose(tr["xs"][1], [0.5, 0.75, 0.8, 1.5], rtol=0, atol=1e-15), tr["xs"][1]
+        assert tr["fs"][0] == 0.5 * (4 + 1 + 4 + 4)
+        assert abs(tr["fs"][1] - 0.5 * (1.5 ** 2 + 0.75 ** 2 + 1.8 ** 2 + 1.5 ** 2)) <= 1e-15
+        assert tr["code"] in (mma_twin.XTOL_REACHED, mma_twin.FTOL_REACHED)
+        assert np.max(np.abs(tr["x"] - np.clip(c, lb, ub))) <= 1e-8, tr["x"]
+        assert np.all(np.diff(np.minimum.accumulate(tr["fs"])) <= 0)
+        assert np.all(tr["xs"] >= np.asarray(lb) - 1e-15) and np.all(tr["xs"] <= np.asarray(ub) + 1e-15)
+
+
+def test_known_answer_move_limit(oracle_mod):
+    """A gradient so steep that the separable minimiser would go to the asymptote: c = -99, box [0, 2], x0 = 1 gives
+    d = 100, |d| sigma = 100, r = 100 / 100.5, dx = -(r) / (1 + sqrt(1 - r^2)) = -0.9049 < -0.9 sigma: the move limit
+    puts the first trial point at exactly x0 - 0.9 sigma = 0.1 (mma.c: |dx| <= 0.9 sigma)."""
+    for tr in _both([1.0], [-99.0], [1.0], [0.0], [2.0], 3, oracle_mod=oracle_mod):
+        assert abs(tr["xs"][1][0] - 0.1) <= 1e-16
+        assert tr["nevals"] == 3 and tr["code"] == mma_twin.MAXEVAL_REACHED
+
+
+def test_twin_and_header_agree_on_fresh_random_quadratics(oracle_mod):
+    """Beyond the committed goldens: random separable quadratics in 1 .. 30 dimensions, random boxes (some of zero
+    width: sigma = 0), every stop rule — traces equal to 1e-12."""
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        n = int(rng.integers(1, 31))
+        a, c = rng.uniform(0.1, 50.0, n), rng.uniform(-5, 5, n)
+        lb = rng.uniform(-4, 0, n)
+        ub = lb + rng.uniform(0.5, 6, n)
+        if it % 5 == 0:
+            ub[0] = lb[0]
+        x0 = rng.uniform(lb - 0.5, ub + 0.5)       # sometimes outside: both clamp the start into the box
+        stop = [(60, 0.0, 0.0), (300, 1e-6, 0.0), (300, 0.0, 1e-5), (300, 1e-9, 1e-7)][it % 4]
+        tw, hd = _both(a, c, x0, lb, ub, *stop, oracle_mod=oracle_mod)
+        assert tw["nevals"] == hd["nevals"] and tw["code"] == hd["code"], (it, tw["nevals"], hd["nevals"])
+        assert np.max(np.abs(tw["xs"] - hd["xs"]) / np.maximum(1.0, np.abs(hd["xs"]))) <= TOL
+        assert np.max(np.abs(tw["fs"] - hd["fs"]) / np.maximum(1e-300, np.abs(hd["fs"]))) <= TOL
+    with pytest.raises(ValueError):       # NLopt's own rule for a start outside the box
+        mma_twin.minimize(lambda x: (0.0, x * 0), [5.0], [0.0], [1.0], 5, start_outside="reject")

@@ -433,3 +433,33 @@ def test_optimizer_with_fp32_evaluations(scene, oracle_mod, gtop, B, m, fusion):
     back = ctx.optimize_batch_ex(b.x, lb, ub, evals)
     for a, r in zip(back, (x64, c64, n64, code64)):
         assert np.array_equal(a, r)
+
+
+@pytest.mark.parametrize("name", ["m3_maxeval", "m6_ftol", "m4_xtol", "m8_both_tols"])
+def test_device_loop_lands_where_the_committed_traces_end(gtop, oracle_mod, name):
+    """tests/golden/mma_traces.npz holds evaluation-by-evaluation traces of the serial optimizer that TWO restatements of
+    NLopt's LD_MMA sharing no code agree on to 1e-12 (oracle/mma_twin.py and csrc/mma.hpp, tests/test_mma_twin.py).  The
+    device's one-launch loop, given the same problem, stop rules and bounds, must end where they end: the same
+    evaluation count and stop code, the best point and its cost to 1e-6."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mma_traces.npz"))
+    g = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+    grid = tuple(int(v) for v in g["grid"])
+    occ = np.unpackbits(g["occupancy"])[:int(np.prod(grid))].reshape(grid)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(g["map_size"], g["origin"], float(g["resolution"]))
+    assert tuple(ctx.grid) == grid
+    pts = (np.argwhere(occ == 1) + 0.5) * float(g["resolution"]) + g["origin"]
+    ctx.update_sdf_map(pts)
+    sdf = oracle_mod.Sdf.from_map_size(g["origin"], float(g["resolution"]), g["map_size"])
+    sdf.build_from_occupancy(occ)
+    assert np.array_equal(ctx.get_sdf().reshape(-1), sdf.dist)
+    ctx.set_params(**{k: float(v) for k, v in zip(("ws", "wc"), g["params"]) if not np.isnan(v)})
+    ctx.set_problem(g["T"][None], g["Df"][None])
+    maxeval, ftol, xtol = int(g["stop"][0]), float(g["stop"][1]), float(g["stop"][2])
+    xs, costs, nev, code = ctx.optimize_batch_ex(g["x0"][None], g["lb"][None], g["ub"][None], maxeval, ftol_rel=ftol,
+                                                 xtol_rel=xtol)
+    ctx.close()
+    assert int(nev[0]) == int(g["nevals"]) and int(code[0]) == int(g["code"]), (nev, code, g["nevals"], g["code"])
+    assert abs(costs[0] - float(g["minf"])) <= 1e-6 * abs(float(g["minf"]))
+    assert np.max(np.abs(xs[0] - g["x"])) <= 1e-6 * max(1.0, np.max(np.abs(g["x"])))
