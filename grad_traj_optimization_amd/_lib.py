@@ -122,6 +122,8 @@ def load_library():
         "gtop_get_cost_curve": (C.c_int, [vp, dp, dp, C.c_int, ip]),
         "gtop_clear_cost_curve": (C.c_int, [vp]),
         "gtop_set_launch_geometry": (C.c_int, [vp, C.c_int, C.c_int]),
+        "gtop_update_sdf_map_window": (C.c_int, [vp, dp, dp, dp, C.c_int]),
+        "gtop_update_sdf_map_window_device": (C.c_int, [vp, dp, dp, vp, C.c_int, vp]),
         "gtop_device_clock_stamp": (C.c_int, [vp, vp, vp]),
         "gtop_device_clock_hz": (C.c_int, [vp, dp]),
         "gtop_rendezvous_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
@@ -247,6 +249,22 @@ class GtopContext:
         st = stream if stream is not None else torch.cuda.current_stream()
         self._chk(self._L.gtop_update_sdf_map_device(self._h, C.c_void_p(pts.data_ptr()), pts.shape[0],
                                                      C.c_void_p(st.cuda_stream)))
+
+    def update_sdf_map_window(self, min_pos, max_pos, pts):
+        """The reference's local update (compare2.cpp:147-152): resetBuffer(min, max), setOccupancy per point,
+        updateESDF3d over the box (gtop_update_sdf_map_window)."""
+        pts = _f64(pts).reshape(-1, 3)
+        mn, mx = _f64(min_pos).reshape(3), _f64(max_pos).reshape(3)
+        self._chk(self._L.gtop_update_sdf_map_window(self._h, _p(mn), _p(mx), _p(pts) if pts.size else None, pts.shape[0]))
+
+    def update_sdf_map_window_device(self, min_pos, max_pos, pts, stream=None):
+        import torch
+        assert pts.is_cuda and pts.dtype == torch.float64 and pts.dim() == 2 and pts.shape[1] == 3
+        pts = pts.contiguous()
+        mn, mx = _f64(min_pos).reshape(3), _f64(max_pos).reshape(3)
+        st = stream if stream is not None else torch.cuda.current_stream()
+        self._chk(self._L.gtop_update_sdf_map_window_device(self._h, _p(mn), _p(mx), C.c_void_p(pts.data_ptr()),
+                                                            pts.shape[0], C.c_void_p(st.cuda_stream)))
 
     def get_sdf(self):
         g = (C.c_int * 3)()

@@ -4,6 +4,7 @@
 // gfx950 device every entry point fails (GTOP_ERR_NO_DEVICE).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -458,6 +459,78 @@ int gtop_update_sdf_map_device(gtop_ctx *c, const void *d_pts, int npts, void *h
   HIPCHK(c, hipSetDevice(c->device));
   return update_sdf_map_on_stream(c, static_cast<const double *>(d_pts), npts, static_cast<hipStream_t>(hip_stream),
                                   /*convert_now=*/true);
+} GTOP_CATCH_STATUS(c)
+
+// The window of (min_pos, max_pos) in voxel indices, as resetBuffer(min, max) and setUpdateRange compute it
+// (sdf_map.cpp:28-45, :244-260): both positions clamped to [min_range, max_range], then posToIndex(min_pos) and
+// posToIndex(max_pos - res/2).  Indices are clipped into the grid (memory safety only: they are inside already).
+static void window_ids(const GtopGrid &g, const double min_pos[3], const double max_pos[3], int lo[3], int hi[3]) {
+  const int n[3] = {g.nx, g.ny, g.nz};
+  for (int i = 0; i < 3; ++i) {
+    const double a = std::max(min_pos[i], g.min_range[i]), b = std::min(max_pos[i], g.max_range[i]);
+    lo[i] = (int)std::floor((a - g.origin[i]) * g.res_inv);                      // posToIndex, :71-74
+    hi[i] = (int)std::floor(((b - g.res / 2) - g.origin[i]) * g.res_inv);
+    lo[i] = std::max(lo[i], 0);
+    hi[i] = std::min(hi[i], n[i] - 1);
+  }
+}
+
+// resetBuffer(min, max) + setOccupancy per point + setUpdateRange(min, max) + updateESDF3d, then the corner records of
+// the voxels that changed; launches on `s`, no synchronisation
+static int update_window_on_stream(gtop_ctx *c, const double min_pos[3], const double max_pos[3], const double *d_pts,
+                                   int npts, hipStream_t s, bool convert_now) {
+  const GtopGrid &g = c->grid;
+  const size_t nvox = (size_t)g.nx * g.ny * g.nz;
+  int lo[3], hi[3];
+  window_ids(g, min_pos, max_pos, lo, hi);
+  int rc;
+  if ((rc = ensure(c, &c->occ, &c->cap_occ, nvox))) return rc;
+  if ((rc = ensure(c, &c->tmp1, &c->cap_tmp1, nvox))) return rc;
+  if ((rc = ensure(c, &c->tmp2, &c->cap_tmp2, nvox))) return rc;
+  const bool empty = hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2];
+  const bool whole = !empty && lo[0] == 0 && lo[1] == 0 && lo[2] == 0 && hi[0] == g.nx - 1 && hi[1] == g.ny - 1 && hi[2] == g.nz - 1;
+  if (whole)   // the window is the map: the whole-grid builder (same results: every distance is 10000 after the reset)
+    return update_sdf_map_on_stream(c, d_pts, npts, s, convert_now);
+  HIPCHK(c, gtop_launch_esdf_window_reset(g, lo, hi, c->occ, c->sdf64, s));
+  HIPCHK(c, gtop_launch_esdf_mark(g, d_pts, npts, c->occ, s));   // (anywhere in the map: setOccupancy does not look at the window)
+  HIPCHK(c, gtop_launch_esdf_window_build(g, lo, hi, c->occ, c->tmp1, c->tmp2, c->sdf64, s));
+  if (empty) return GTOP_OK;
+  // Only the records that hold a voxel of the window change.  fp32 records that are current stay current (their window
+  // is rebuilt in the same pass); stale ones cannot be made current by a window: they are rebuilt whole where this
+  // entry's rule says fp32 must follow (the capturable device entry, or a context that runs fp32 evaluations), and
+  // stay stale — to be rebuilt at the first fp32 use — otherwise.
+  if (c->rec32_ok) return build_records_on_stream(c, s, true, lo, hi);
+  if ((rc = build_records_on_stream(c, s, false, lo, hi))) return rc;
+  if (convert_now || c->fp32_in_use) return fp32_records_ready(c, s);
+  return GTOP_OK;
+}
+
+int gtop_update_sdf_map_window(gtop_ctx *c, const double min_pos[3], const double max_pos[3], const double *pts,
+                               int npts) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!min_pos || !max_pos || npts < 0 || (npts > 0 && !pts)) return fail(c, GTOP_ERR_INVALID, "update window: bad arguments");
+  if (!c->have_grid || !c->own64 || !c->occ || !c->rec64_ok)
+    return fail(c, GTOP_ERR_STATE, "update window: call gtop_init_sdf_map first");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if (npts > 0) {
+    if ((rc = ensure(c, &c->d_pts, &c->pts_cap, (size_t)npts * 3))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, (size_t)npts * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  if ((rc = update_window_on_stream(c, min_pos, max_pos, c->d_pts, npts, c->stream, /*convert_now=*/false))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
+int gtop_update_sdf_map_window_device(gtop_ctx *c, const double min_pos[3], const double max_pos[3], const void *d_pts,
+                                      int npts, void *hip_stream) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!min_pos || !max_pos || npts < 0 || (npts > 0 && !d_pts)) return fail(c, GTOP_ERR_INVALID, "update window: bad arguments");
+  if (!c->have_grid || !c->own64 || !c->occ || !c->rec64_ok)
+    return fail(c, GTOP_ERR_STATE, "update window: call gtop_init_sdf_map first");
+  HIPCHK(c, hipSetDevice(c->device));
+  return update_window_on_stream(c, min_pos, max_pos, static_cast<const double *>(d_pts), npts,
+                                 static_cast<hipStream_t>(hip_stream), /*convert_now=*/true);
 } GTOP_CATCH_STATUS(c)
 
 int gtop_get_sdf(gtop_ctx *c, double *dist_host, int grid_out[3]) try {

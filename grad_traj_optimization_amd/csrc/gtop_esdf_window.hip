@@ -1,0 +1,135 @@
+// gtop_esdf_window.hip — the reference's LOCAL map update on the device.
+//
+// compare2.cpp:147-152 / compare22.cpp:145-156 of the reference update a map the way an online planner does: only the
+// box of space the sensor has just seen —
+//     sdf_map.resetBuffer(min_pos, max_pos);           src/sdf_map.cpp:28-53   occupancy 0, distance 10000 in the box
+//     sdf_map.setOccupancy(p) for every point;         :80-99
+//     [sdf_map.setUpdateRange(min_pos, max_pos);]      :244-264                the same box as voxel indices
+//     sdf_map.updateESDF3d();                          :310-368                the three sweeps over min_vec .. max_vec
+// — with these consequences, all kept: the sweeps see only the window's part of every line (an obstacle outside the
+// box casts no distance into it), distances outside the box keep their values, and inside it the result is
+// min(res*sqrt(val), previous) with previous = 10000 after the reset (:355-361).
+//
+// Each sweep computes, per line segment, out(q) = min over v in the segment of (q - v)^2 + in(v) — the minimum the
+// reference's lower-envelope pass (fillESDF, :266-308) finds; on this data every quantity is an exact integer, so the
+// kernels take that minimum directly in int32 with an INF sentinel (see gtop_esdf.hip, whose whole-grid kernels this
+// file's full-window case hands over to), one lane per voxel of the window, lanes along z: the nearest occupied voxel
+// of the column by an outward walk, then two outward scans with the exact cut-off d^2 >= best.  A window is small by
+// its nature (the sensor's range); the kernels are the plain form of the whole-grid ones, without their packed
+// 16-bit scans, candidate lists and slab skipping.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gtop_kernels.h"
+
+namespace {
+
+constexpr int kInf = 0x3fffffff;   // "no obstacle on this line segment" (as gtop_esdf.hip)
+
+struct Window {
+  int lo[3], hi[3];   // inclusive voxel indices
+};
+
+__device__ __forceinline__ bool window_voxel(const GtopGrid &g, const Window &w, int &x, int &y, int &z, size_t &idx) {
+  const int wz = w.hi[2] - w.lo[2] + 1, wy = w.hi[1] - w.lo[1] + 1, wx = w.hi[0] - w.lo[0] + 1;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)wx * wy * wz) return false;
+  z = w.lo[2] + (int)(t % (size_t)wz);
+  const size_t r = t / (size_t)wz;
+  y = w.lo[1] + (int)(r % (size_t)wy);
+  x = w.lo[0] + (int)(r / (size_t)wy);
+  idx = ((size_t)x * g.ny + y) * g.nz + z;
+  return true;
+}
+
+// resetBuffer(min_pos, max_pos), sdf_map.cpp:46-52
+__global__ void __launch_bounds__(256)
+window_reset_kernel(const GtopGrid g, const Window w, uint8_t *__restrict__ occ, double *__restrict__ dist) {
+  int x, y, z;
+  size_t idx;
+  if (!window_voxel(g, w, x, y, z, idx)) return;
+  occ[idx] = 0;
+  dist[idx] = 10000.0;
+}
+
+// z sweep (:311-326) over z in [lo2, hi2]: squared distance to the nearest occupied voxel of the column segment
+__global__ void __launch_bounds__(256)
+window_z_kernel(const GtopGrid g, const Window w, const uint8_t *__restrict__ occ, int *__restrict__ out) {
+  int x, y, z;
+  size_t idx;
+  if (!window_voxel(g, w, x, y, z, idx)) return;
+  int best = kInf;
+  for (int d = 0;; ++d) {
+    const bool below = z - d >= w.lo[2], above = z + d <= w.hi[2];
+    if (!below && !above) break;
+    if ((below && occ[idx - d] == 1) || (above && occ[idx + d] == 1)) {
+      best = d * d;
+      break;
+    }
+  }
+  out[idx] = best;
+}
+
+// y sweep (:328-345, STRIDE = nz, AXIS = 1) and x sweep (:347-363, STRIDE = ny nz, AXIS = 0; FINAL: res*sqrt, min with
+// the previous distance): out(q) = min_v (q - v)^2 + in(v) over the window's segment of the line, by an outward scan
+// from q with the exact cut-off d^2 >= best (every in(v) >= 0)
+template <int AXIS, bool FINAL>
+__global__ void __launch_bounds__(256)
+window_scan_kernel(const GtopGrid g, const Window w, const int *__restrict__ in, int *__restrict__ out,
+                   double *__restrict__ dist) {
+  int c[3];
+  size_t idx;
+  if (!window_voxel(g, w, c[0], c[1], c[2], idx)) return;
+  const size_t stride = AXIS == 1 ? (size_t)g.nz : (size_t)g.ny * g.nz;
+  const int q = c[AXIS], lo = w.lo[AXIS], hi = w.hi[AXIS];
+  int best = in[idx];
+  for (int d = 1;; ++d) {
+    const int d2 = d * d;
+    if (d2 >= best) break;
+    const bool below = q - d >= lo, above = q + d <= hi;
+    if (!below && !above) break;
+    if (below) {
+      const int v = in[idx - (size_t)d * stride];
+      if (v < kInf) best = min(best, d2 + v);   // (d <= 2^15, v < kInf: below 2^31)
+    }
+    if (above) {
+      const int v = in[idx + (size_t)d * stride];
+      if (v < kInf) best = min(best, d2 + v);
+    }
+  }
+  if constexpr (FINAL) {
+    // :355-361: min(res*sqrt(val), previous); a line segment without obstacles has val = DBL_MAX there: previous stays
+    if (best < kInf) {
+      const double r = g.res * sqrt((double)best);
+      const double old = dist[idx];
+      dist[idx] = r < old ? r : old;
+    }
+  } else {
+    out[idx] = best;
+  }
+}
+
+}  // namespace
+
+// lo / hi: the window as resetBuffer / setUpdateRange compute it (inclusive voxel indices, inside the grid).
+// reset: resetBuffer(min, max).  Then the caller marks its points (gtop_launch_esdf_mark) and calls build.
+hipError_t gtop_launch_esdf_window_reset(const GtopGrid &g, const int lo[3], const int hi[3], uint8_t *occ, double *dist,
+                                         hipStream_t stream) {
+  Window w{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+  const long long n = (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+  if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]) return hipSuccess;
+  hipLaunchKernelGGL(window_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, w, occ, dist);
+  return hipGetLastError();
+}
+
+hipError_t gtop_launch_esdf_window_build(const GtopGrid &g, const int lo[3], const int hi[3], const uint8_t *occ, int *tmp1,
+                                         int *tmp2, double *dist, hipStream_t stream) {
+  if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]) return hipSuccess;
+  Window w{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+  const long long n = (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipLaunchKernelGGL(window_z_kernel, grid, block, 0, stream, g, w, occ, tmp1);
+  hipLaunchKernelGGL((window_scan_kernel<1, false>), grid, block, 0, stream, g, w, (const int *)tmp1, tmp2, dist);
+  hipLaunchKernelGGL((window_scan_kernel<0, true>), grid, block, 0, stream, g, w, (const int *)tmp2, (int *)nullptr, dist);
+  return hipGetLastError();
+}

@@ -100,6 +100,13 @@ size_t gtop_esdf_rows_ints(const GtopGrid &g);   // ints of row workspace the bu
 hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,
                                   double *dist, float *dist32, hipStream_t stream);
 
+// the local update of compare2.cpp:147-152 (gtop_esdf_window.hip): resetBuffer(min, max) over the inclusive voxel box
+// lo .. hi, and updateESDF3d over the same box (sdf_map.cpp:28-53, :310-368)
+hipError_t gtop_launch_esdf_window_reset(const GtopGrid &g, const int lo[3], const int hi[3], uint8_t *occ, double *dist,
+                                         hipStream_t stream);
+hipError_t gtop_launch_esdf_window_build(const GtopGrid &g, const int lo[3], const int hi[3], const uint8_t *occ, int *tmp1,
+                                         int *tmp2, double *dist, hipStream_t stream);
+
 // ---- corner records (gtop_records.hip): the gather-friendly resident copy the lookups read ----
 size_t gtop_record_count(const GtopGrid &g);   // (nx+1)(ny+1)(nz+2) records of 4 values
 // S -> D in {double -> double, double -> float, float -> float}; rec32 (may be NULL): the fp32 records too, in the

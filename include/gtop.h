@@ -124,6 +124,25 @@ int gtop_update_sdf_map(gtop_ctx *ctx, const double *obstacle_pts, int npts);
  * written by the last sweep beside the fp64 field, so the call can be captured
  * into a hipGraph and replayed with fp32 evaluations behind it. */
 int gtop_update_sdf_map_device(gtop_ctx *ctx, const void *d_obstacle_pts, int npts, void *hip_stream);
+/* The reference's LOCAL map update — what compare2.cpp:147-152 does per sensor frame:
+ *   sdf_map.resetBuffer(min_pos, max_pos)     src/sdf_map.cpp:28-53
+ *   sdf_map.setOccupancy(p) for every point   :80-99
+ *   [setUpdateRange(min_pos, max_pos)]        :244-264
+ *   sdf_map.updateESDF3d()                    :310-368, its loops over min_vec .. max_vec
+ * with its semantics: the box is clamped to the map and turned into voxel indices as
+ * the reference does (posToIndex(min_pos) .. posToIndex(max_pos - res/2)); inside
+ * it occupancy is cleared and distances reset to 10000; the points are marked
+ * wherever in the map they fall; the three sweeps run over the box only and see
+ * only the box's part of every line (an obstacle outside casts no distance into
+ * it); distances outside the box keep their values, inside they become
+ * min(res*sqrt(val), 10000).  Only the corner records of the box are rebuilt, so
+ * the cost follows the box, not the map.  A box that covers the whole map takes
+ * the whole-grid builder (same results).  Occupancy persists between calls, as in
+ * the reference.  The _device form takes the points in HBM and only enqueues. */
+int gtop_update_sdf_map_window(gtop_ctx *ctx, const double min_pos[3], const double max_pos[3],
+                               const double *obstacle_pts, int npts);
+int gtop_update_sdf_map_window_device(gtop_ctx *ctx, const double min_pos[3], const double max_pos[3],
+                                      const void *d_obstacle_pts, int npts, void *hip_stream);
 /* Copy the resident fp64 distance field back to the host (nx*ny*nz doubles). */
 int gtop_get_sdf(gtop_ctx *ctx, double *dist_host, int grid_out[3]);
 

@@ -547,6 +547,68 @@ void oracle_esdf_build(const oracle_sdf *S, const double *occupancy,
   free(tmp2);
 }
 
+/* sdf_map.cpp:28-45 / :244-260: the voxel window of (min_pos, max_pos) as resetBuffer(min, max) and setUpdateRange
+ * compute it — both clamp the positions to [min_range, max_range], then posToIndex(min_pos) and
+ * posToIndex(max_pos - res/2). */
+void oracle_window_ids(const oracle_sdf *S, const double min_pos_in[3],
+                       const double max_pos_in[3], int min_id[3], int max_id[3]) {
+  double min_pos[3], max_pos[3], shifted[3];
+  for (int i = 0; i < 3; ++i) {
+    min_pos[i] = min_pos_in[i] > S->min_range[i] ? min_pos_in[i] : S->min_range[i];   /* max(min_pos, min_range) */
+    max_pos[i] = max_pos_in[i] < S->max_range[i] ? max_pos_in[i] : S->max_range[i];   /* min(max_pos, max_range) */
+    shifted[i] = max_pos[i] - S->resolution / 2;
+  }
+  sdf_pos_to_index(S, min_pos, min_id);
+  sdf_pos_to_index(S, shifted, max_id);
+}
+
+/* sdf_map.cpp:28-53: resetBuffer(min_pos, max_pos) — occupancy 0 and distance 10000 inside the window only. */
+void oracle_reset_window(const oracle_sdf *S, double *occupancy, double *distance,
+                         const double min_pos[3], const double max_pos[3]) {
+  int lo[3], hi[3];
+  oracle_window_ids(S, min_pos, max_pos, lo, hi);
+  int gy = S->grid[1], gz = S->grid[2];
+  for (int x = lo[0]; x <= hi[0]; ++x)
+    for (int y = lo[1]; y <= hi[1]; ++y)
+      for (int z = lo[2]; z <= hi[2]; ++z) {
+        occupancy[(size_t)x * gy * gz + (size_t)y * gz + z] = 0.0;
+        distance[(size_t)x * gy * gz + (size_t)y * gz + z] = 10000;
+      }
+}
+
+/* sdf_map.cpp:310-368 with the window min_vec .. max_vec that setUpdateRange (:244-264) left behind: the three sweeps
+ * run over the window only and see only the window's part of every line; distances outside keep their values, inside
+ * they become min(res*sqrt(val), previous) (:355-361).  tmp1 / tmp2 are the object's tmp_buffer1 / tmp_buffer2. */
+void oracle_esdf_build_window(const oracle_sdf *S, const double *occupancy,
+                              double *distance, const int lo[3], const int hi[3]) {
+  int gx = S->grid[0], gy = S->grid[1], gz = S->grid[2];
+  size_t N = (size_t)gx * gy * gz;
+  double *tmp0 = (double *)malloc(sizeof(double) * N);
+  double *tmp1 = (double *)calloc(N, sizeof(double));
+  double *tmp2 = (double *)calloc(N, sizeof(double));
+  for (size_t i = 0; i < N; ++i) tmp0[i] = occupancy[i] == 1 ? 0 : DBL_MAX;
+  int n = gx > gy ? (gx > gz ? gx : gz) : (gy > gz ? gy : gz);
+  for (int x = lo[0]; x <= hi[0]; x++)
+    for (int y = lo[1]; y <= hi[1]; y++) {
+      size_t base = (size_t)x * gy * gz + (size_t)y * gz;
+      fill_esdf(tmp0 + base, 1, tmp1 + base, 1, lo[2], hi[2], n, 0, 0.0);
+    }
+  for (int x = lo[0]; x <= hi[0]; x++)
+    for (int z = lo[2]; z <= hi[2]; z++) {
+      size_t base = (size_t)x * gy * gz + z;
+      fill_esdf(tmp1 + base, (size_t)gz, tmp2 + base, (size_t)gz, lo[1], hi[1], n, 0, 0.0);
+    }
+  for (int y = lo[1]; y <= hi[1]; y++)
+    for (int z = lo[2]; z <= hi[2]; z++) {
+      size_t base = (size_t)y * gz + z;
+      fill_esdf(tmp2 + base, (size_t)gy * gz, distance + base, (size_t)gy * gz, lo[0], hi[0], n, 1,
+                S->resolution);
+    }
+  free(tmp0);
+  free(tmp1);
+  free(tmp2);
+}
+
 /* ------------------------------------------------------------------ */
 /* the hot path                                                       */
 /* ------------------------------------------------------------------ */

@@ -54,6 +54,14 @@ int oracle_set_occupancy(const oracle_sdf *S, double *occupancy,
                          const double pos[3], int occ);
 void oracle_esdf_build(const oracle_sdf *S, const double *occupancy,
                        double *distance);
+/* the windowed update (sdf_map.cpp:28-53 resetBuffer(min, max), :244-264 setUpdateRange, :310-368 updateESDF3d over
+ * min_vec .. max_vec) */
+void oracle_window_ids(const oracle_sdf *S, const double min_pos[3], const double max_pos[3], int min_id[3],
+                       int max_id[3]);
+void oracle_reset_window(const oracle_sdf *S, double *occupancy, double *distance, const double min_pos[3],
+                         const double max_pos[3]);
+void oracle_esdf_build_window(const oracle_sdf *S, const double *occupancy, double *distance, const int lo[3],
+                              const int hi[3]);
 
 double oracle_cost_grad(int m, const double *L, const double *R,
                         const double *Df, const double *T,

@@ -74,6 +74,13 @@ def lib():
         L.oracle_set_occupancy.restype = C.c_int
         L.oracle_esdf_build.argtypes = [C.POINTER(OracleSdf), dp, dp]
         L.oracle_esdf_build.restype = None
+        ip3 = C.POINTER(C.c_int)
+        L.oracle_window_ids.argtypes = [C.POINTER(OracleSdf), dp, dp, ip3, ip3]
+        L.oracle_window_ids.restype = None
+        L.oracle_reset_window.argtypes = [C.POINTER(OracleSdf), dp, dp, dp, dp]
+        L.oracle_reset_window.restype = None
+        L.oracle_esdf_build_window.argtypes = [C.POINTER(OracleSdf), dp, dp, ip3, ip3]
+        L.oracle_esdf_build_window.restype = None
         L.oracle_cost_grad.argtypes = [C.c_int, dp, dp, dp, dp, C.POINTER(OracleParams),
                                        C.POINTER(OracleSdf), dp, dp]
         L.oracle_cost_grad.restype = C.c_double
@@ -214,6 +221,26 @@ class Sdf:
         occ = _f64(occ).reshape(-1)
         self.dist[:] = 10000.0
         lib().oracle_esdf_build(C.byref(self.c), _p(occ), _p(self.dist))
+
+    def window_ids(self, min_pos, max_pos):
+        """The voxel window resetBuffer(min, max) / setUpdateRange compute (sdf_map.cpp:28-45, :244-260)."""
+        lo, hi = (C.c_int * 3)(), (C.c_int * 3)()
+        lib().oracle_window_ids(C.byref(self.c), _p(_f64(min_pos)), _p(_f64(max_pos)), lo, hi)
+        return np.array(lo[:]), np.array(hi[:])
+
+    def update_window(self, occ, min_pos, max_pos, pts):
+        """The reference's local map update (compare2.cpp:147-152): resetBuffer(min, max), setOccupancy per point,
+        setUpdateRange(min, max), updateESDF3d — on the persistent occupancy array `occ` (float64, one per voxel) and
+        this object's distances.  Distances outside the window keep their values."""
+        assert occ.dtype == np.float64 and occ.size == self.dist.size and occ.flags.c_contiguous
+        mn, mx = _f64(min_pos), _f64(max_pos)
+        lib().oracle_reset_window(C.byref(self.c), _p(occ), _p(self.dist), _p(mn), _p(mx))
+        for p in _f64(pts).reshape(-1, 3):
+            lib().oracle_set_occupancy(C.byref(self.c), _p(occ), _p(_f64(p)), 1)
+        lo, hi = (C.c_int * 3)(), (C.c_int * 3)()
+        lib().oracle_window_ids(C.byref(self.c), _p(mn), _p(mx), lo, hi)
+        lib().oracle_esdf_build_window(C.byref(self.c), _p(occ), _p(self.dist), lo, hi)
+        return np.array(lo[:]), np.array(hi[:])
 
 
 def cost_grad(T, Df, x, sdf, params, L=None, R=None):
