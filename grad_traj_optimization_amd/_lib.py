@@ -679,6 +679,24 @@ class GtopGroup:
             out.append((c, g))
         return out
 
+    def launch_resident(self, x=None, gather=1):
+        """eval_resident without waiting: the slices' evaluations and the all-gather are only ENQUEUED on the members'
+        streams (gtop_group_eval_resident(synchronize = 0)); read the results with read_gathered() after synchronize()."""
+        if x is not None:
+            x = _f64(x)
+            self._chk(self._L.gtop_group_upload_x(self._h, x.shape[0], _p(x)))
+        self._chk(self._L.gtop_group_eval_resident(self._h, int(gather), 0))
+
+    def synchronize(self):
+        self._chk(self._L.gtop_group_synchronize(self._h))
+
+    def read_gathered(self, member, grads=False):
+        n = 9 * (self.m - 1)
+        c = np.empty(self.B)
+        g = np.empty((self.B, n)) if grads else None
+        self._chk(self._L.gtop_group_read_gathered(self._h, int(member), _p(c), _p(g) if grads else None))
+        return c, g
+
     def optimize_batch_ex(self, x0, lb, ub, max_evals, ftol_rel=0.0, xtol_rel=0.0, maxtime=0.0):
         x = _f64(x0).copy()
         B = x.shape[0]

@@ -56,13 +56,25 @@ constexpr int red_stride(int spl) {
 // else reads.  Never defined in the shipped library.
 #ifdef GTOP_STAMPS
 __device__ unsigned long long g_gtop_stamps[4096][16];
+// -DGTOP_STAMPS=2: only the wavefront's first and last stamp (0 and 11) — two s_memtime instead of twelve, so that the
+// wavefront's lifetime is (nearly) the uninstrumented one; slots 12 / 13 then hold the constant-rate wall clock
+// (wall_clock64, 100 MHz) at the same two points: lifetimes in seconds, and the shader clock's rate from the two.
+#if GTOP_STAMPS == 2
+#define GTOP_STAMP_WANTED(i) ((i) == 0 || (i) == 11)
+#else
+#define GTOP_STAMP_WANTED(i) true
+#endif
 #define GTOP_STAMP(i)                                                                          \
   do {                                                                                         \
-    unsigned long long t_;                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtop_stamps[blockIdx.x][i] = t_;              \
+    if (GTOP_STAMP_WANTED(i)) {                                                                \
+      unsigned long long t_;                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtop_stamps[blockIdx.x][i] = t_;            \
+      if (((i) == 0 || (i) == 11) && threadIdx.x == 0 && blockIdx.x < 4096)                    \
+        g_gtop_stamps[blockIdx.x][(i) == 0 ? 12 : 13] = wall_clock64();                        \
+    }                                                                                          \
   } while (0)
 // where the wavefront runs (HW_ID: wave/simd/cu/sh/se; XCC_ID), into stamp slots 14 and 15
 #define GTOP_STAMP_HWID()                                                                      \
@@ -899,7 +911,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     // the hand-issued loads hold all 12 corner pairs at once — 4.45 against 4.23 us
     expk.pin();
   }
-#ifdef GTOP_STAMPS
+#if defined(GTOP_STAMPS) && GTOP_STAMPS != 2   // (the first / last stamp build adds no waits)
   GTOP_STAMP(2);   // inputs requested
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   GTOP_STAMP(3);   // inputs landed
@@ -1070,6 +1082,12 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       // (Only the latency variant: with other wavefronts on the SIMD the straight-line selects are cheaper than the
       // branch — measured, B = 16 384 fp64: 34.4 us with the selects, 37.6 with the branch.)
       constexpr bool kRareOut = CH == SPL;
+      // one sample at a time (the throughput bodies): the sample's four corner loads first, everything that does not
+      // need them — velocity, speed, its reciprocal — while they are in flight
+#ifndef GTOP_LOADS_FIRST
+#define GTOP_LOADS_FIRST 1
+#endif
+      constexpr bool kLoadsFirst = GTOP_LOADS_FIRST && CH == 1 && !LONG;   // (the chunked body, on the two-wavefront budget: 3 % slower with it, measured)
       [[maybe_unused]] float pmin[3], pmax[3];
       [[maybe_unused]] bool outs[CH];
       // (the position polynomial in double — fp32 kernels: from the double coefficients and the double sample time)
@@ -1098,9 +1116,11 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
             pmin[k] = c == 0 ? pf : fminf(pmin[k], pf);
             pmax[k] = c == 0 ? pf : fmaxf(pmax[k], pf);
           }
-          vels[c][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
-          if constexpr (DYN)   // getAccelerationFromCoeff, :491-505 (through `float` like the other two)
-            accs[c][k] = round_through_float((R)2 * q[k][2] + K.k6 * q[k][3] * t + (R)12 * q[k][4] * t2 + (R)20 * q[k][5] * t3);
+          if constexpr (!kLoadsFirst) {
+            vels[c][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
+            if constexpr (DYN)   // getAccelerationFromCoeff, :491-505 (through `float` like the other two)
+              accs[c][k] = round_through_float((R)2 * q[k][2] + K.k6 * q[k][3] * t + (R)12 * q[k][4] * t2 + (R)20 * q[k][5] * t3);
+          }
         }
         if constexpr (ASMLD) taps[c] = sdf_issue_asm(a, ibox, pos[0], pos[1], pos[2], raw[c]);
         else taps[c] = sdf_issue<R, WIDE>(a, ibox, pos[0], pos[1], pos[2]);   // :363
@@ -1116,7 +1136,21 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         any_out = __ballot(lane_out) != 0ull;   // wave-uniform, rare
       }
       if (j0 == 0) GTOP_STAMP(4);   // corner loads issued
-      if constexpr (CH == SPL) GTOP_PHASE_FENCE();   // every corner load is issued above this line ...
+      if constexpr (CH == SPL || kLoadsFirst) GTOP_PHASE_FENCE();   // every corner load is issued above this line ...
+      if constexpr (kLoadsFirst) {
+        // ... one sample at a time: the velocity (and the speeds below) behind the loads.  Without the fence the
+        // compiler, short of registers, loaded one record, waited, and only then loaded the other into the same
+        // registers: two exposed round trips per sample.
+        const R t = (R)ts[0];
+        const R t2 = t * t, t3 = t2 * t, t4 = t2 * t2;
+        const R d2 = (R)2 * t, d3 = K.k3 * t2, d4 = (R)4 * t3, d5 = K.k5 * t4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          vels[0][k] = round_through_float(q[k][1] + q[k][2] * d2 + q[k][3] * d3 + q[k][4] * d4 + q[k][5] * d5);
+          if constexpr (DYN)
+            accs[0][k] = round_through_float((R)2 * q[k][2] + K.k6 * q[k][3] * t + (R)12 * q[k][4] * t2 + (R)20 * q[k][5] * t3);
+        }
+      }
       // ... and what does not need them runs while they are in flight: the jerk term and the speeds
       if constexpr (MINW <= 2) jerk_init();
       R vns[CH], ivns[CH];
@@ -1126,7 +1160,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         vns[c] = speed_sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + K.eps;   // :358
         ivns[c] = quick_rcp(vns[c]);
       }
-#ifdef GTOP_STAMPS
+#if defined(GTOP_STAMPS) && GTOP_STAMPS != 2
       if (j0 == 0) {
         asm volatile("" ::"v"(vns[0]), "v"(ivns[CH - 1]), "v"(acc[18]), "v"(acc[3]));
         GTOP_STAMP(5);   // in-flight work done
@@ -1232,7 +1266,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     (void)wdt; (void)pen_d0; (void)pen_inv_r; (void)pen_alpha; (void)pen_gd;
     jerk_init();
   }
-#ifdef GTOP_STAMPS
+#if defined(GTOP_STAMPS) && GTOP_STAMPS != 2
   asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[11]), "v"(acc[17]), "v"(acc[18]));
   GTOP_STAMP(7);   // stage B done
 #endif

@@ -191,3 +191,65 @@ def test_cpp_batch_class_with_fp32_evaluations(tmp_path):
     r = json.loads(out.stdout[out.stdout.index("{"):])
     assert r["B"] == 60 and r["min_evals"] == r["max_evals"] == 20
     assert r["max_rel_cost_diff"] <= 2e-4 and r["max_coeff_diff"] <= 1e-9, r
+
+
+def test_new_problem_while_a_gather_is_in_flight(scene, gtop):
+    """Regression for the race e18f164 closed (round 3, no test then): gtop_group_eval_resident(synchronize = 0) leaves
+    the slices' kernels and every member's copies into the OTHER members' gathered rows in flight; a
+    gtop_group_set_problem right behind it (another batch size: buffers are reused, grown, memset) must wait for all of
+    them — every member's stream, not just the buffer owner's — before it touches anything.  Alternating a large and a
+    small problem with nothing in between but the enqueue: every result must still be the unsharded evaluation's."""
+    mp, ctx = scene
+    g = _group(gtop, mp, [0, 0, 0])
+    assert g.gather_backend == "copy" and "listed more than once" in g.gather_note()
+    ctx.set_params()
+    sizes = [(6000, 6, 1), (37, 6, 2), (9000, 6, 3), (5, 4, 4), (7000, 12, 5), (64, 6, 6)]
+    refs = []
+    for B, m, seed in sizes:
+        b = problem.make_trajectories(B, m, mp, seed=300 + seed, step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0))
+        ctx.set_problem(b.T, b.Df)
+        refs.append((b, ctx.eval_batch(b.x)))
+    for rep in range(3):
+        for (b, (c_ref, g_ref)) in refs:
+            g.set_problem(b.T, b.Df)              # behind whatever the previous round left in flight
+            g.launch_resident(b.x, gather=2)      # enqueue only
+            if rep == 2:                          # last pass: look at what every member holds
+                g.synchronize()
+                for i in range(3):
+                    c, gr = g.read_gathered(i, grads=True)
+                    assert np.array_equal(c, c_ref) and np.array_equal(gr, g_ref), (len(c_ref), i)
+    g.close()
+
+
+def test_more_than_one_distinct_device(gtop):
+    """The paths only n > 1 DISTINCT devices take — ncclCommInitAll over several ordinals, one all-gather per device in
+    a group call, cross-device events, the replicated map built on every card — need a multi-GPU box: skipped on the
+    one-GPU boxes this repository has had, so those paths are UNVERIFIED ON HARDWARE (README)."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"needs at least 2 GPUs ({n} visible): the n > 1 distinct-device paths have not run on hardware")
+    mp = problem.make_map((60, 50, 30), density=0.03, seed=11)
+    ctx = gtop.GtopContext(device=0)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map(mp.obstacle_points())
+    ctx.set_params()
+    devs = list(range(min(n, 6)))
+    for force in ("rccl", "copy"):
+        import os
+        os.environ["GTOP_GROUP_GATHER"] = force
+        try:
+            g = _group(gtop, mp, devs)
+        finally:
+            del os.environ["GTOP_GROUP_GATHER"]
+        assert g.gather_backend == force, g.gather_note()
+        for B, m in ((4099, 6), (257, 12)):
+            b = problem.make_trajectories(B, m, mp, seed=500 + B, step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0))
+            ctx.set_problem(b.T, b.Df)
+            c_ref, g_ref = ctx.eval_batch(b.x)
+            g.set_problem(b.T, b.Df)
+            c, gr = g.eval_batch(b.x)
+            assert np.array_equal(c, c_ref) and np.array_equal(gr, g_ref)
+            for ci, gi in g.eval_resident(gather=2):
+                assert np.array_equal(ci, c_ref) and np.array_equal(gi, g_ref)
+        g.close()

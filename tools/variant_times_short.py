@@ -10,7 +10,8 @@ import grad_traj_optimization_amd as gtop  # noqa: E402
 from grad_traj_optimization_amd import problem  # noqa: E402
 from bench import _time_evals  # noqa: E402
 
-mp = problem.make_map(200, density=0.02, seed=0)
+GRID = int(os.environ.get("GTOP_GRID", "200"))          # GTOP_GRID=400: the field of configs[4] (4 % occupied)
+mp = problem.make_map(GRID, density=0.02 if GRID <= 200 else 0.04, seed=0 if GRID <= 200 else 2)
 ctx = gtop.GtopContext(device=0)
 ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
 ctx.update_sdf_map(mp.obstacle_points())
@@ -29,4 +30,4 @@ for spec in sys.argv[1:]:
     T = torch.tensor(b.T, dtype=td, device=dev)
     ctx.set_params(**prm)
     us = _time_evals(ctx, x, Df, T, 600)
-    print(f"B={B:6d} m={m:3d} {dt} {'dyn' if prm else '   '} spl=0: {us:8.2f} us", flush=True)
+    print(f"B={B:6d} m={m:3d} {dt} {'dyn' if prm else '   '} g{GRID} spl=0: {us:8.2f} us", flush=True)
