@@ -106,7 +106,7 @@ def dominant_kernel(m, B, dtype, pinned):
         return "gtop_eval_wave_kernel (pinned samples per lane)"
     tail = "(anonymous namespace)::GtopNoMma, false, "
     if m <= 6:
-        if B >= (8192 if dtype == "f32" else 12288):
+        if B >= (2048 if dtype == "f32" else 4096):
             return f"gtop_eval_wave_kernel<{R}, false, 6, 2, true, 3, {tail}false>"   # two trajectories per wavefront (fp32: packed pairs)
         return f"gtop_eval_wave_kernel<{R}, false, 3, 1, true, {3 if B >= 3072 else 2}, {tail}false>"
     if m <= 12 and B <= (1024 if dtype == "f64" else 512):

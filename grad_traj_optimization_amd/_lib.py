@@ -679,6 +679,16 @@ class GtopGroup:
             out.append((c, g))
         return out
 
+    def set_launch_geometry(self, waves=0, samples_per_lane=0):
+        """gtop_set_launch_geometry on every member's context (pins the kernel body: a slice and the whole batch then
+        sum in the same order whatever their sizes)."""
+        self._L.gtop_group_context.restype = C.c_void_p
+        for i in range(len(self.devices)):
+            ctx = C.c_void_p(self._L.gtop_group_context(self._h, i))
+            rc = self._L.gtop_set_launch_geometry(ctx, int(waves), int(samples_per_lane))
+            if rc != 0:
+                raise GtopError(rc, self._L.gtop_last_error(ctx).decode())
+
     def launch_resident(self, x=None, gather=1):
         """eval_resident without waiting: the slices' evaluations and the all-gather are only ENQUEUED on the members'
         streams (gtop_group_eval_resident(synchronize = 0)); read the results with read_gathered() after synchronize()."""

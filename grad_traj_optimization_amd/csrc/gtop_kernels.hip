@@ -1419,7 +1419,10 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 }
 
 #ifndef GTOP_TWO_PER_WAVE_F64_FROM
-#define GTOP_TWO_PER_WAVE_F64_FROM 12288
+#define GTOP_TWO_PER_WAVE_F64_FROM 4096
+#endif
+#ifndef GTOP_TWO_PER_WAVE_F32_FROM
+#define GTOP_TWO_PER_WAVE_F32_FROM 2048
 #endif
 #ifndef GTOP_TWO_WAVES_UP_TO
 #define GTOP_TWO_WAVES_UP_TO 1024   // trajectories of 7 .. 12 segments: two wavefronts each up to this batch (2 048 wavefronts)
@@ -1452,9 +1455,11 @@ bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimize
   p.nw = 1;
   // (two trajectories per wavefront at five lanes per segment amortise the per-lane set-up — coefficients, jerk term,
   // A^-T — over six samples instead of three: fewer instructions per trajectory, longer chains per wavefront; it wins
-  // once the batch fills the chip several times over — measured on one box, fp64: B = 8 192 19.6 us either way,
-  // 16 384: 32.5 against 34.6, 65 536: 118 against 128; fp32, packed pairs: from 8 192)
-  if (m <= 6) p.spl = pinned_spl ? pinned_spl : ((B >= (elem == 4 ? 8192 : GTOP_TWO_PER_WAVE_F64_FROM) && !for_optimizer) ? 6 : 3);
+  // once the batch puts several wavefronts on every SIMD.  Round 4, corner records and the sample's loads issued
+  // together (one box, us, ten lanes | five lanes per segment): fp64 B = 3 072 8.0 | 9.1, 4 096 10.4 | 9.7, 8 192 18.6 |
+  // 16.9, 16 384 36.9 | 30.7 — from 4 096 (round 3: 12 288); fp32, packed pairs: 2 048 5.25 | 4.90, 4 096 8.3 | 7.4,
+  // 16 384 27.0 | 23.5 — from 2 048 (round 3: 8 192))
+  if (m <= 6) p.spl = pinned_spl ? pinned_spl : ((B >= (elem == 4 ? GTOP_TWO_PER_WAVE_F32_FROM : GTOP_TWO_PER_WAVE_F64_FROM) && !for_optimizer) ? 6 : 3);
   else if (m <= 12 && !for_optimizer && pinned_spl != 6 &&
            (pinned_spl == 3 || B <= (elem == 4 ? GTOP_TWO_WAVES_UP_TO / 2 : GTOP_TWO_WAVES_UP_TO))) {
     // 7 .. 12 segments, a batch that leaves SIMDs idle with one wavefront per trajectory: two wavefronts per

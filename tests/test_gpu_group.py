@@ -203,6 +203,10 @@ def test_new_problem_while_a_gather_is_in_flight(scene, gtop):
     g = _group(gtop, mp, [0, 0, 0])
     assert g.gather_backend == "copy" and "listed more than once" in g.gather_note()
     ctx.set_params()
+    # (the auto rule picks the body from the batch size: a slice of 2 000 rows and the whole batch of 6 000 would sum
+    # in different orders — pin five lanes per segment on both sides)
+    ctx.set_launch_geometry(0, 6)
+    g.set_launch_geometry(0, 6)
     sizes = [(6000, 6, 1), (37, 6, 2), (9000, 6, 3), (5, 4, 4), (7000, 12, 5), (64, 6, 6)]
     refs = []
     for B, m, seed in sizes:
@@ -219,6 +223,7 @@ def test_new_problem_while_a_gather_is_in_flight(scene, gtop):
                     c, gr = g.read_gathered(i, grads=True)
                     assert np.array_equal(c, c_ref) and np.array_equal(gr, g_ref), (len(c_ref), i)
     g.close()
+    ctx.set_launch_geometry(0, 0)
 
 
 def test_more_than_one_distinct_device(gtop):

@@ -142,7 +142,7 @@ def test_configs3_batch_in_eight_shards_equals_the_whole(gtop):
     """BASELINE.json configs[3] at full size on one card: 131 072 trajectories over the 200^3 field, evaluated whole
     and as the eight contiguous 16 384-row shards the eight ranks of `bench.py --gpus 8 --batch 16384` would own.
     Rows are independent and the auto rule picks the same body for a shard as for the whole batch (both past the
-    12 288-row switch to two trajectories per wavefront), so the concatenation is bit-identical; plus cost >= 1e-3 (:417-418) and finite gradients."""
+    4 096-row switch to two trajectories per wavefront), so the concatenation is bit-identical; plus cost >= 1e-3 (:417-418) and finite gradients."""
     import torch
     mp = problem.make_map(200, density=0.02, seed=0)
     ctx = gtop.GtopContext(device=0)
