@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Rebuild profiles/traffic.json — what bench.py reads for roofline.traffic, roofline.launch_us.rocprof and
-roofline_issue — from the round's committed rocprofv3 outputs under profiles/r3/: the PMC summaries
+roofline_issue — from the round's committed rocprofv3 outputs under profiles/r4/: the PMC summaries
 (tools/pmc_collect.sh + tools/pmc_summary.py: fabric traffic, issued instructions per wavefront) and the
 --kernel-trace --stats CSVs of the same bench commands (average launch time of the evaluation kernel)."""
 import csv
@@ -8,7 +8,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = "r3"
+RND = "r4"
 KEYS = {"B1024_m6_g200_f64": ("summary_B1024_f64.json", "kernel_stats_default_B1024_f64.csv"),
         "B16384_m6_g200_f64": ("summary_B16384_f64.json", "kernel_stats_B16384_f64.csv"),
         "B16384_m6_g200_f32": ("summary_B16384_f32.json", "kernel_stats_B16384_f32.csv"),
