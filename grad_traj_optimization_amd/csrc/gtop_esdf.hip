@@ -24,7 +24,7 @@
 //             obstacle-free stretches cost nothing;
 //   x sweep : outward scan v = q-1, q+1, q-2, ... with the same cut-off (in(v) >= 0);
 //             it also applies the final res*sqrt(.) (exactly rounded fp64, as the
-//             reference's).  The fp32 copy used by the GTOP_F32 path is made by the
+//             reference's).  (Round 4: the GTOP_F32 path reads fp32 corner records, gtop_records.hip; dist32 is NULL.)  The fp32 copy used by the GTOP_F32 path was made by the
 //             caller on first use (a third of the sweep's writes).
 // What bounds the scans, and what this file does about it (measured, profiles/r2/esdf_kernels.txt):
 //   * the texture-address unit takes 16 cycles per wave64 load whatever its width, so a lane owns 4 voxels

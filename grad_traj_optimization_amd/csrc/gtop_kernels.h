@@ -76,8 +76,6 @@ bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimize
 template <typename R>
 hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &plan, bool dyn, hipStream_t stream);
 
-hipError_t gtop_launch_f64_to_f32(const double *src, float *dst, size_t nelem,
-                                  hipStream_t stream);
 // minmax[0] = min(minmax[0], clock), minmax[1] = max(minmax[1], clock) of the device's constant-rate wall clock
 hipError_t gtop_launch_clock_stamp(unsigned long long *minmax, hipStream_t stream);
 
@@ -94,7 +92,8 @@ hipError_t gtop_launch_esdf_reset(uint8_t *occ, double *dist, size_t nvox, hipSt
 hipError_t gtop_launch_esdf_mark(const GtopGrid &g, const double *pts, int npts, uint8_t *occ,
                                  hipStream_t stream);
 // updateESDF3d (sdf_map.cpp:310-368): the three sweeps z, y, x as exact integer minimisations,
-// then res*sqrt(.) into dist (fp64) and dist32 (fp32 copy).  tmp1/tmp2: nvox int32 each.
+// then res*sqrt(.) into dist (fp64; dist32, an fp32 copy, may be NULL and is since round 4: the fp32 path reads fp32
+// corner records).  tmp1/tmp2: nvox int32 each.
 bool gtop_esdf_supported(const GtopGrid &g);
 size_t gtop_esdf_rows_ints(const GtopGrid &g);   // ints of row workspace the builder needs
 hipError_t gtop_launch_esdf_build(const GtopGrid &g, const uint8_t *occ, int *tmp1, int *tmp2, int *rows,

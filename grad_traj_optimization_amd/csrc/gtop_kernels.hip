@@ -1592,18 +1592,6 @@ template hipError_t gtop_launch_eval<double>(const GtopKernelArgs<double> &, con
 template hipError_t gtop_launch_eval<float>(const GtopKernelArgs<float> &, const GtopEvalPlan &, bool, hipStream_t);
 
 // ---------------------------------------------------------------------------
-// fp64 -> fp32 copy of the distance field for the GTOP_F32 path
-// ---------------------------------------------------------------------------
-namespace {
-__global__ void __launch_bounds__(256)
-gtop_f64_to_f32_kernel(const double *__restrict__ src, float *__restrict__ dst, size_t nelem) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < nelem; i += stride) dst[i] = (float)src[i];
-}
-}  // namespace
-
-// ---------------------------------------------------------------------------
 // Device-side clock stamp (gtop_device_clock_stamp): one lane reads the constant-rate wall clock (the counter the
 // optimizer loop's maxtime rule uses) and folds it into minmax[0] = earliest, minmax[1] = latest stamp.  Captured as
 // the first and the last node of a graph of evaluation launches, latest - earliest is the GPU's own time for the
@@ -1621,11 +1609,5 @@ __global__ void __launch_bounds__(64) gtop_clock_stamp_kernel(unsigned long long
 
 hipError_t gtop_launch_clock_stamp(unsigned long long *minmax, hipStream_t stream) {
   hipLaunchKernelGGL(gtop_clock_stamp_kernel, dim3(1), dim3(64), 0, stream, minmax);
-  return hipGetLastError();
-}
-
-hipError_t gtop_launch_f64_to_f32(const double *src, float *dst, size_t nelem, hipStream_t stream) {
-  if (nelem == 0) return hipSuccess;
-  hipLaunchKernelGGL(gtop_f64_to_f32_kernel, dim3(2048), dim3(256), 0, stream, src, dst, nelem);
   return hipGetLastError();
 }

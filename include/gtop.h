@@ -120,9 +120,9 @@ int gtop_update_sdf_map(gtop_ctx *ctx, const double *obstacle_pts, int npts);
 /* The same with the obstacle points (npts x 3 doubles, xyz-contiguous) already in
  * HBM: launches on `hip_stream` and returns without synchronising — the build is
  * five kernels, 0.08 ms for a 200^3 map, against 0.6 ms of PCIe for the points of
- * the host form.  The fp32 copy of the field (if the context holds one) is
- * written by the last sweep beside the fp64 field, so the call can be captured
- * into a hipGraph and replayed with fp32 evaluations behind it. */
+ * the host form.  The corner records of BOTH precisions are rebuilt behind the
+ * sweeps on the same stream, so the call can be captured into a hipGraph and
+ * replayed with fp64 or fp32 evaluations behind it. */
 int gtop_update_sdf_map_device(gtop_ctx *ctx, const void *d_obstacle_pts, int npts, void *hip_stream);
 /* The reference's LOCAL map update — what compare2.cpp:147-152 does per sensor frame:
  *   sdf_map.resetBuffer(min_pos, max_pos)     src/sdf_map.cpp:28-53
@@ -460,7 +460,7 @@ int gtop_set_launch_geometry(gtop_ctx *ctx, int waves, int samples_per_lane);
  * per iteration; 0 = separate update launch.  Same arithmetic in all three. */
 int gtop_set_optimizer_fusion(gtop_ctx *ctx, int fused);
 /* Batched optimizer: the arithmetic of its EVALUATIONS.  GTOP_F64 (default) is
- * the reference's; GTOP_F32 runs them on the fp32 copy of the field in the
+ * the reference's; GTOP_F32 runs them on the fp32 corner records in the
  * packed-fp32 bodies of gtop_eval_device(GTOP_F32) — the trial point, bounds,
  * Df, T, the CCSA-MMA update and every result stay fp64, so the interface of
  * gtop_optimize_* does not change.  Measured: 9 % less time for 1 024
