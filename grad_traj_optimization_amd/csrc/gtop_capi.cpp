@@ -66,6 +66,9 @@ struct gtop_ctx {
   uint64_t poll_sentinel = 0;    // preset of the polled output slots (GTOP_POLL_SENTINEL=<hex> overrides: tests)
   double *d_pts = nullptr;
   size_t cap_occ = 0, cap_tmp1 = 0, cap_tmp2 = 0, cap_rows = 0, pts_cap = 0;
+  uint8_t *win_occ = nullptr;    // gtop_update_sdf_map_window: the window's occupancy / distances as a compact grid
+  double *win_dist = nullptr;
+  size_t cap_win_occ = 0, cap_win_dist = 0;
 
   // problem set by gtop_set_problem
   int B = 0, m = 0, t_stride = 0;
@@ -329,7 +332,7 @@ int gtop_destroy(gtop_ctx *c) try {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   release_sdf(c);
-  void *bufs[] = {c->rec64, c->rec32, c->occ, c->tmp1, c->tmp2, c->rows, c->boxes, c->d_q, c->d_pts,
+  void *bufs[] = {c->win_occ, c->win_dist, c->rec64, c->rec32, c->occ, c->tmp1, c->tmp2, c->rows, c->boxes, c->d_q, c->d_pts,
                   c->d_T, c->d_Df, c->d_x, c->d_cost, c->d_grad,
                   c->mma_vec, c->mma_scal, c->mma_int, c->mma_f, c->mma_g, c->mma_lb, c->mma_ub, c->mma_res};
   for (void *p : bufs)
@@ -493,8 +496,25 @@ static int update_window_on_stream(gtop_ctx *c, const double min_pos[3], const d
     return update_sdf_map_on_stream(c, d_pts, npts, s, convert_now);
   HIPCHK(c, gtop_launch_esdf_window_reset(g, lo, hi, c->occ, c->sdf64, s));
   HIPCHK(c, gtop_launch_esdf_mark(g, d_pts, npts, c->occ, s));   // (anywhere in the map: setOccupancy does not look at the window)
-  HIPCHK(c, gtop_launch_esdf_window_build(g, lo, hi, c->occ, c->tmp1, c->tmp2, c->sdf64, s));
   if (empty) return GTOP_OK;
+  // The sweeps over the window see nothing outside it: the update IS the whole-grid transform of the window taken alone.
+  // A window of at least 12 x 12 x 3 voxels therefore goes through the whole-grid builder (gtop_esdf.hip: packed 16-bit
+  // scans, candidate lists, slab skipping) on a compact copy of its occupancy, and the result is written back into the
+  // window — 10x less time per voxel than the plain window kernels, which serve the slivers.
+  const int wx = hi[0] - lo[0] + 1, wy = hi[1] - lo[1] + 1, wz = hi[2] - lo[2] + 1;
+  GtopGrid sub = g;
+  sub.nx = wx; sub.ny = wy; sub.nz = wz;
+  if (wx >= 12 && wy >= 12 && wz >= 3 && gtop_esdf_supported(sub)) {
+    const size_t nsub = (size_t)wx * wy * wz;
+    if ((rc = ensure(c, &c->rows, &c->cap_rows, gtop_esdf_rows_ints(g)))) return rc;   // (sized for the whole grid: covers any window)
+    if ((rc = ensure(c, &c->win_occ, &c->cap_win_occ, nsub))) return rc;
+    if ((rc = ensure(c, &c->win_dist, &c->cap_win_dist, nsub))) return rc;
+    HIPCHK(c, gtop_launch_esdf_window_gather(g, lo, hi, c->occ, c->win_occ, s));
+    HIPCHK(c, gtop_launch_esdf_build(sub, c->win_occ, c->tmp1, c->tmp2, c->rows, c->win_dist, nullptr, s));
+    HIPCHK(c, gtop_launch_esdf_window_scatter(g, lo, hi, c->win_dist, c->sdf64, s));
+  } else {
+    HIPCHK(c, gtop_launch_esdf_window_build(g, lo, hi, c->occ, c->tmp1, c->tmp2, c->sdf64, s));
+  }
   // Only the records that hold a voxel of the window change.  fp32 records that are current stay current (their window
   // is rebuilt in the same pass); stale ones cannot be made current by a window: they are rebuilt whole where this
   // entry's rule says fp32 must follow (the capturable device entry, or a context that runs fp32 evaluations), and

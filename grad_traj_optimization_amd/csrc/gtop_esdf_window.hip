@@ -13,10 +13,12 @@
 // Each sweep computes, per line segment, out(q) = min over v in the segment of (q - v)^2 + in(v) — the minimum the
 // reference's lower-envelope pass (fillESDF, :266-308) finds; on this data every quantity is an exact integer, so the
 // kernels take that minimum directly in int32 with an INF sentinel (see gtop_esdf.hip, whose whole-grid kernels this
-// file's full-window case hands over to), one lane per voxel of the window, lanes along z: the nearest occupied voxel
-// of the column by an outward walk, then two outward scans with the exact cut-off d^2 >= best.  A window is small by
-// its nature (the sensor's range); the kernels are the plain form of the whole-grid ones, without their packed
-// 16-bit scans, candidate lists and slab skipping.
+// file's full-window case hands over to).  Because the sweeps never look outside the window, the update IS the
+// whole-grid transform of the window taken alone: gtop_capi.cpp gathers the occupancy of a window of at least
+// 12 x 12 x 3 voxels into a compact grid (window_gather_kernel), runs gtop_esdf.hip's builder on it and writes the
+// result back (window_scatter_kernel).  The plain kernels below — one lane per voxel of the window, lanes along z: the
+// nearest occupied voxel of the column by an outward walk, then two outward scans with the exact cut-off
+// d^2 >= best — serve the slivers (10x the time per voxel: no packed 16-bit scans, candidate lists or slab skipping).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -109,7 +111,43 @@ window_scan_kernel(const GtopGrid g, const Window w, const int *__restrict__ in,
   }
 }
 
+// The window's occupancy as a compact grid of its own, and the compact grid's distances back into the window: a
+// windowed update IS the whole-grid transform of the window taken alone (its sweeps never look outside it), so windows
+// that are large enough go through gtop_esdf.hip's optimised builder on the compact copy.
+__global__ void __launch_bounds__(256)
+window_gather_kernel(const GtopGrid g, const Window w, const uint8_t *__restrict__ occ, uint8_t *__restrict__ sub) {
+  int x, y, z;
+  size_t idx;
+  if (!window_voxel(g, w, x, y, z, idx)) return;
+  sub[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = occ[idx];
+}
+
+__global__ void __launch_bounds__(256)
+window_scatter_kernel(const GtopGrid g, const Window w, const double *__restrict__ sub, double *__restrict__ dist) {
+  int x, y, z;
+  size_t idx;
+  if (!window_voxel(g, w, x, y, z, idx)) return;
+  // :355-361: min(res*sqrt(val), previous), previous = 10000 after the reset; the compact build's values are <= 10000
+  dist[idx] = sub[(size_t)blockIdx.x * blockDim.x + threadIdx.x];
+}
+
 }  // namespace
+
+hipError_t gtop_launch_esdf_window_gather(const GtopGrid &g, const int lo[3], const int hi[3], const uint8_t *occ,
+                                          uint8_t *sub, hipStream_t stream) {
+  Window w{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+  const long long n = (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+  hipLaunchKernelGGL(window_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, w, occ, sub);
+  return hipGetLastError();
+}
+
+hipError_t gtop_launch_esdf_window_scatter(const GtopGrid &g, const int lo[3], const int hi[3], const double *sub,
+                                           double *dist, hipStream_t stream) {
+  Window w{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+  const long long n = (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+  hipLaunchKernelGGL(window_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, w, sub, dist);
+  return hipGetLastError();
+}
 
 // lo / hi: the window as resetBuffer / setUpdateRange compute it (inclusive voxel indices, inside the grid).
 // reset: resetBuffer(min, max).  Then the caller marks its points (gtop_launch_esdf_mark) and calls build.

@@ -105,6 +105,11 @@ hipError_t gtop_launch_esdf_window_reset(const GtopGrid &g, const int lo[3], con
                                          hipStream_t stream);
 hipError_t gtop_launch_esdf_window_build(const GtopGrid &g, const int lo[3], const int hi[3], const uint8_t *occ, int *tmp1,
                                          int *tmp2, double *dist, hipStream_t stream);
+// the window's occupancy as a compact grid (z fastest) / a compact grid's distances into the window
+hipError_t gtop_launch_esdf_window_gather(const GtopGrid &g, const int lo[3], const int hi[3], const uint8_t *occ,
+                                          uint8_t *sub, hipStream_t stream);
+hipError_t gtop_launch_esdf_window_scatter(const GtopGrid &g, const int lo[3], const int hi[3], const double *sub,
+                                           double *dist, hipStream_t stream);
 
 // ---- corner records (gtop_records.hip): the gather-friendly resident copy the lookups read ----
 size_t gtop_record_count(const GtopGrid &g);   // (nx+1)(ny+1)(nz+2) records of 4 values
