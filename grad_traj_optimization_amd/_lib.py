@@ -124,6 +124,7 @@ def load_library():
         "gtop_set_launch_geometry": (C.c_int, [vp, C.c_int, C.c_int]),
         "gtop_update_sdf_map_window": (C.c_int, [vp, dp, dp, dp, C.c_int]),
         "gtop_update_sdf_map_window_device": (C.c_int, [vp, dp, dp, vp, C.c_int, vp]),
+        "gtop_set_field_precisions": (C.c_int, [vp, C.c_int]),
         "gtop_device_clock_stamp": (C.c_int, [vp, vp, vp]),
         "gtop_device_clock_hz": (C.c_int, [vp, dp]),
         "gtop_rendezvous_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
@@ -344,6 +345,10 @@ class GtopContext:
                                            C.c_void_p(cost.data_ptr()), C.c_void_p(grad.data_ptr()),
                                            C.c_void_p(stream)))
         return cost, grad
+
+    def set_field_precisions(self, keep_fp32=True):
+        """False: keep fp64 corner records only (the capturable map updates then skip the fp32 pass; fp32 evaluations fail)."""
+        self._chk(self._L.gtop_set_field_precisions(self._h, 1 if keep_fp32 else 0))
 
     def clock_stamp(self, minmax, stream=None):
         """Enqueue a device-clock stamp: minmax (torch int64 tensor of 2 on the device, preset to [2**63 - 1, 0])

@@ -50,6 +50,7 @@ struct gtop_ctx {
   bool rec64_ok = false, rec32_ok = false;   // the records hold the current field
   bool rec32_stale = false;          // ... or must be rebuilt from sdf64 before the next fp32 use
   bool fp32_in_use = false;
+  bool fp32_wanted = true;           // gtop_set_field_precisions: 0 = fp64 records only (fp32 evaluations refused)
 
   // ESDF construction workspace
   uint8_t *occ = nullptr;
@@ -204,6 +205,7 @@ int own_sdf_buffers(gtop_ctx *c, size_t nvox) {
 // Corner records of the fp64 field on stream `s` (the whole field, or the voxel box [vlo, vhi]); the fp32 records too
 // when they are wanted now, otherwise they are marked stale and the first fp32 use builds them.
 int build_records_on_stream(gtop_ctx *c, hipStream_t s, bool fp32_now, const int *vlo = nullptr, const int *vhi = nullptr) {
+  fp32_now = fp32_now && c->fp32_wanted;
   // (both precisions in one pass over the field when both are wanted)
   HIPCHK(c, (gtop_launch_build_records<double, double>(c->grid, c->sdf64, c->rec64, fp32_now ? c->rec32 : nullptr, vlo, vhi, s)));
   c->rec64_ok = true;
@@ -219,6 +221,8 @@ int build_records_on_stream(gtop_ctx *c, hipStream_t s, bool fp32_now, const int
 
 // the fp32 records, current, before an fp32 use enqueued on stream `s`
 int fp32_records_ready(gtop_ctx *c, hipStream_t s) {
+  if (!c->fp32_wanted)
+    return fail(c, GTOP_ERR_STATE, "fp32 evaluation on a context whose fp32 records are switched off (gtop_set_field_precisions)");
   c->fp32_in_use = true;
   if (c->rec32_ok) return GTOP_OK;
   if (!c->rec32_stale || !c->sdf64) return fail(c, GTOP_ERR_STATE, "no fp32 distance field resident");
@@ -521,7 +525,7 @@ static int update_window_on_stream(gtop_ctx *c, const double min_pos[3], const d
   // stay stale — to be rebuilt at the first fp32 use — otherwise.
   if (c->rec32_ok) return build_records_on_stream(c, s, true, lo, hi);
   if ((rc = build_records_on_stream(c, s, false, lo, hi))) return rc;
-  if (convert_now || c->fp32_in_use) return fp32_records_ready(c, s);
+  if ((convert_now || c->fp32_in_use) && c->fp32_wanted) return fp32_records_ready(c, s);
   return GTOP_OK;
 }
 
@@ -1157,6 +1161,17 @@ int gtop_device_clock_hz(gtop_ctx *c, double *hz) try {
   HIPCHK(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
   if (khz <= 0) return fail(c, GTOP_ERR_HIP, "hipDeviceAttributeWallClockRate reports no wall clock");
   *hz = 1e3 * (double)khz;
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
+int gtop_set_field_precisions(gtop_ctx *c, int keep_fp32) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (keep_fp32 != 0 && keep_fp32 != 1) return fail(c, GTOP_ERR_INVALID, "field precisions: 0 (fp64 records only) or 1 (fp32 records too)");
+  c->fp32_wanted = keep_fp32 != 0;
+  if (!c->fp32_wanted) {
+    c->rec32_ok = false;
+    c->rec32_stale = c->sdf64 != nullptr;   // (switched on again: rebuilt from the fp64 field at the first fp32 use)
+  }
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)
 

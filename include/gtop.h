@@ -453,6 +453,15 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
  * Other values are GTOP_ERR_INVALID at the call.  Results do not depend on the
  * geometry beyond fp summation order. */
 int gtop_set_launch_geometry(gtop_ctx *ctx, int waves, int samples_per_lane);
+/* The corner records every lookup reads exist in fp64 and fp32; the capturable
+ * map-update entries (gtop_update_sdf_map_device, _window_device) rebuild both
+ * so that a replayed graph leaves both current — a third of their record pass
+ * (200^3: 98 us for both against 57 us for fp64 alone).  keep_fp32 = 0 tells the
+ * context that it will never run fp32 evaluations: only fp64 records are kept,
+ * and GTOP_F32 evaluations (and gtop_set_optimizer_precision(GTOP_F32) runs) fail
+ * with GTOP_ERR_STATE.  1 (default) switches them back on; they are rebuilt from
+ * the fp64 field at the next fp32 use. */
+int gtop_set_field_precisions(gtop_ctx *ctx, int keep_fp32);
 /* Batched optimizer: 2 (default) = one launch runs the whole loop (evaluate,
  * MMA update, evaluate, ... max_evals times) for every trajectory — they are
  * independent, so nothing has to return to the host or to HBM in between;

@@ -715,3 +715,33 @@ def test_contexts_in_concurrent_host_threads(gtop, oracle_mod):
     sdf.build_from_occupancy(jobs[3][0].occupancy)
     c_ref, g_ref, _ = oracle_mod.eval_batch(jobs[3][1].T, jobs[3][1].Df, jobs[3][1].x, sdf, oracle_mod.make_params(), nthreads=8)
     assert np.max(np.abs(serial[3][0][0] - c_ref) / np.abs(c_ref)) <= 1e-5
+
+
+def test_field_precisions_knob(scene, oracle_mod, gtop):
+    """gtop_set_field_precisions(0): a context that never runs fp32 evaluations keeps fp64 corner records only — the
+    capturable map update skips the fp32 pass — and an fp32 evaluation is refused (GTOP_ERR_STATE) instead of reading
+    records that are not there; switched back on, the fp32 records are rebuilt from the current field at the next use."""
+    import torch
+    mp, ctx0, sdf = scene
+    dev = torch.device("cuda:0")
+    b = problem.make_trajectories(64, 6, mp, seed=77)
+    c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params())
+    ctx = gtop.GtopContext(device=0)
+    ctx.set_field_precisions(False)
+    ctx.init_sdf_map(mp.map_size, mp.origin, mp.resolution)
+    ctx.update_sdf_map_device(torch.tensor(mp.obstacle_points(), device=dev))
+    torch.cuda.synchronize()
+    x64, Df64, T64 = (torch.tensor(a, device=dev) for a in (b.x, b.Df.reshape(-1, 18), b.T))
+    c, g = ctx.eval_device(x64, Df64, T64)
+    torch.cuda.synchronize()
+    rc, rg = scenes.rel_err(c.cpu().numpy(), g.cpu().numpy(), c_ref, g_ref)
+    assert rc <= TOL64 and rg <= TOL64
+    with pytest.raises(gtop.GtopError) as e:
+        ctx.eval_device(x64.float(), Df64.float(), T64.float())
+    assert e.value.code == 4
+    ctx.set_field_precisions(True)
+    c32, g32 = ctx.eval_device(x64.float(), Df64.float(), T64.float())
+    torch.cuda.synchronize()
+    rc, rg = scenes.rel_err(c32.double().cpu().numpy(), g32.double().cpu().numpy(), c_ref, g_ref)
+    assert rc <= TOL32 and rg <= TOL32
+    ctx.close()
