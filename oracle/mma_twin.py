@@ -87,7 +87,7 @@ def separable_minimiser(x, fx, dfdx, sigma, rho, lb, ub):
     return y, g, w
 
 
-def minimize(f, x0, lb, ub, maxeval, ftol_rel=0.0, xtol_rel=0.0, start_outside="clamp", observe=None):
+def minimize(f, x0, lb, ub, maxeval, ftol_rel=0.0, xtol_rel=0.0, start_outside="clamp", observe=None, observe_outer=None, trace=None):
     """f(x) -> (value, gradient).  Returns dict(x, minf, nevals, code, xs, fs): best point, its value, evaluations used,
     nlopt_result-style code, and the trace (every evaluation's point and value, in order).
 
@@ -95,7 +95,9 @@ def minimize(f, x0, lb, ub, maxeval, ftol_rel=0.0, xtol_rel=0.0, start_outside="
     clamps it into the box instead ("clamp", the default here so that the two can be compared; "reject" raises).
     observe(xcur, fcur, g, fbest): called after every inner evaluation with the trial point, its value, the
     approximant's value there and the best value before it — the two comparisons the road hangs on are g >= fcur
-    (conservative: the inner loop ends) and fcur < fbest (the best point moves)."""
+    (conservative: the inner loop ends) and fcur < fbest (the best point moves).
+    observe_outer(xcur, xprev, xprevprev): called before every asymptote update (k > 1) — the third kind of decision
+    the road hangs on: per coordinate the SIGN of (xcur - xprev)(xprev - xprevprev) picks the factor 0.7, 1 or 1.2."""
     lb = np.asarray(lb, dtype=np.float64)
     ub = np.asarray(ub, dtype=np.float64)
     x = np.array(x0, dtype=np.float64)
@@ -131,6 +133,8 @@ def minimize(f, x0, lb, ub, maxeval, ftol_rel=0.0, xtol_rel=0.0, start_outside="
             xcur, g, w = separable_minimiser(x, fx, dfdx, sigma, rho, lb, ub)
             fcur, dfcur = evaluate(xcur)
             inner_done = g >= fcur
+            if trace is not None:      # (diagnostics: the state each trial point was made from)
+                trace.append(dict(rho=rho, g=g, w=w, f=fcur, fbest=fx, k=k, sigma_min=float(np.min(sigma)), sigma_max=float(np.max(sigma))))
             if observe is not None:
                 observe(xcur, fcur, g, fx)
             if fcur < fx:
@@ -152,6 +156,8 @@ def minimize(f, x0, lb, ub, maxeval, ftol_rel=0.0, xtol_rel=0.0, start_outside="
             break
         rho = max(0.1 * rho, RHO_MIN)
         if k > 1:
+            if observe_outer is not None:
+                observe_outer(xcur, xprev, xprevprev)
             for j in range(n):
                 s = (xcur[j] - xprev[j]) * (xprev[j] - xprevprev[j])
                 sigma[j] *= 0.7 if s < 0 else (1.2 if s > 0 else 1.0)
