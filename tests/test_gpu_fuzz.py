@@ -145,8 +145,9 @@ def test_random_draw_fp32(gtop, oracle_mod, seed):
     # :383-407): its penalties are exp((|a| - a0) / r_a) of an acceleration that fp32 forms as a cancelling sum of
     # terms up to 20 q5 t^3 — on these draws' half-second segments |a| reaches hundreds of m/s^2 with an absolute error
     # of 1e-5 of the largest term, i.e. up to 0.1 m/s^2, and exp turns an absolute error da into a relative one of
-    # da / r_a: 1e-2 (7.5e-3 seen in 1 000 dyn draws, 5e-3 in the first 160).
-    tol = 1e-2 if kw.get("enable_dyn") else (TOL32 if m <= 12 else 1e-3)
+    # da / r_a: 1e-2 (7.5e-3 seen in 1 000 dyn draws, 5e-3 in the first 160); past 12 segments the chunked body's longer
+    # sums on top of it: 3e-2 (1.2e-2 seen at 13 segments in 2 500 more draws).
+    tol = (1e-2 if m <= 12 else 3e-2) if kw.get("enable_dyn") else (TOL32 if m <= 12 else 1e-3)
     c, g = cd.double().cpu().numpy(), gd.double().cpu().numpy()
     fits = (c_ref < 1e30) & (np.abs(g_ref).max(axis=1) < 1e30)          # rows past fp32's range (3.4e38) may come back inf
     if fits.mean() <= 0.9 and seed >= 100_000:
