@@ -19,7 +19,7 @@
 #include "gtop_guard.h"
 #include "gtop_kernels.h"
 
-#define GTOP_ABI_VERSION 1
+#define GTOP_ABI_VERSION 2   // round 4: gtop_update_sdf_map_window*, gtop_set_field_precisions, gtop_device_clock_*, gtop_group_gather_note, GTOP_ERR_INTERNAL
 
 struct gtop_ctx {
   int device = 0;

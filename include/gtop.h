@@ -75,7 +75,9 @@ int gtop_destroy(gtop_ctx *ctx);
 /* Text of the last error on this context ("" if none); with ctx == NULL,
  * the text of the calling thread's last failed gtop_create. */
 const char *gtop_last_error(const gtop_ctx *ctx);
-/* Library/ABI version, for the loader to check. */
+/* Library/ABI version, for the loader to check (2 since round 4: the windowed map
+ * update, gtop_set_field_precisions, gtop_device_clock_*, gtop_group_gather_note,
+ * GTOP_ERR_INTERNAL; nothing of version 1 changed meaning). */
 int gtop_abi_version(void);
 
 /* ---- configuration -------------------------------------------------- */
