@@ -27,9 +27,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
+#include "gtop_device_common.h"
 #include "gtop_kernels.h"
 
 namespace {
+
+typedef float gtop_rec_f4 __attribute__((ext_vector_type(4)));
 
 template <typename D> struct Half2;   // half a record: the two y-corners of one x column
 template <> struct Half2<double> { double lo, hi; } __attribute__((aligned(16)));
@@ -64,18 +69,42 @@ records_kernel(const S *__restrict__ field, D *__restrict__ rec, float *__restri
   const S *col = field + (size_t)x * ny * nz + z;
   S lo = col[(size_t)min(max(cya - 1, 0), ny - 1) * nz];
   size_t hi_at = 2 * (((size_t)cx * (ny + 1) + cya) * (nz + 2) + cz) + h;   // in half records
-  for (int cy = cya; cy <= cyb; ++cy, hi_at += 2 * (size_t)(nz + 2)) {
-    const S hi = col[(size_t)min(cy, ny - 1) * nz];
-    Half2<D> out;
-    out.lo = (D)lo; out.hi = (D)hi;
-    // non-temporal stores: the records are not read again by this kernel, and there are four bytes of them for every
-    // byte of the field it reads (whole-map rebuild 179 -> 167 us at 200^3, 1 400 -> 1 333 us at 400^3, one box)
-    __builtin_nontemporal_store(out.lo, &reinterpret_cast<Half2<D> *>(rec)[hi_at].lo);
-    __builtin_nontemporal_store(out.hi, &reinterpret_cast<Half2<D> *>(rec)[hi_at].hi);
+  const size_t row = 2 * (size_t)(nz + 2);                                  // half records per cy
+  // non-temporal stores throughout: the records are not read again by this kernel, and there are four bytes of them for
+  // every byte of the field it reads (whole-map rebuild 179 -> 167 us at 200^3, 1 400 -> 1 333 us at 400^3, one box)
+  auto store_half = [&](size_t at, S a, S b) {
+    __builtin_nontemporal_store((D)a, &reinterpret_cast<Half2<D> *>(rec)[at].lo);
+    __builtin_nontemporal_store((D)b, &reinterpret_cast<Half2<D> *>(rec)[at].hi);
+  };
+  if constexpr (std::is_same<D, double>::value) {
     if (rec32) {
-      __builtin_nontemporal_store((float)lo, &reinterpret_cast<Half2<float> *>(rec32)[hi_at].lo);
-      __builtin_nontemporal_store((float)hi, &reinterpret_cast<Half2<float> *>(rec32)[hi_at].hi);
+      // Both precisions.  An fp32 half record is 8 bytes: stored per lane, an instruction carries 512 bytes.  Two rows
+      // at a time instead: the lane pair (2j, 2j+1) — the two halves of one record — trade halves (one DPP quad swap),
+      // lane 2j stores the WHOLE fp32 record of row cy, lane 2j+1 that of row cy + 1: 16 bytes per lane, every lane
+      // busy, one contiguous kilobyte per instruction as for the fp64 records.
+      for (int cy = cya; cy <= cyb; cy += 2, hi_at += 2 * row) {
+        const bool two = cy + 1 <= cyb;       // (the same for both lanes of a pair: they share their tile)
+        const S hiA = col[(size_t)min(cy, ny - 1) * nz];
+        const S hiB = two ? col[(size_t)min(cy + 1, ny - 1) * nz] : hiA;
+        store_half(hi_at, lo, hiA);
+        if (two) store_half(hi_at + row, hiA, hiB);
+        const float s0 = h ? (float)lo : (float)hiA, s1 = h ? (float)hiA : (float)hiB;     // what the partner needs
+        const float r0 = gtop_dpp_move<0xb1>(s0), r1 = gtop_dpp_move<0xb1>(s1);             // quad_perm [1,0,3,2]
+        if (two) {
+          const gtop_rec_f4 out = h ? (gtop_rec_f4){r0, r1, (float)hiA, (float)hiB} : (gtop_rec_f4){(float)lo, (float)hiA, r0, r1};
+          __builtin_nontemporal_store(out, reinterpret_cast<gtop_rec_f4 *>(rec32) + ((hi_at - h) / 2 + (h ? row / 2 : 0)));
+        } else {                              // a last single row: its halves as 8-byte stores
+          __builtin_nontemporal_store((float)lo, &reinterpret_cast<Half2<float> *>(rec32)[hi_at].lo);
+          __builtin_nontemporal_store((float)hiA, &reinterpret_cast<Half2<float> *>(rec32)[hi_at].hi);
+        }
+        lo = hiB;
+      }
+      return;
     }
+  }
+  for (int cy = cya; cy <= cyb; ++cy, hi_at += row) {
+    const S hi = col[(size_t)min(cy, ny - 1) * nz];
+    store_half(hi_at, lo, hi);
     lo = hi;
   }
 }
