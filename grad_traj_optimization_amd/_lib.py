@@ -144,6 +144,7 @@ def load_library():
         "gtop_group_last_error": (C.c_char_p, [vp]),
         "gtop_group_gather_backend": (C.c_char_p, [vp]),
         "gtop_group_gather_note": (C.c_char_p, [vp]),
+        "gtop_group_update_sdf_map_window": (C.c_int, [vp, dp, dp, dp, C.c_int]),
         "gtop_group_set_params": (C.c_int, [vp, C.POINTER(GtopParams)]),
         "gtop_group_init_sdf_map": (C.c_int, [vp, dp, dp, C.c_double]),
         "gtop_group_update_sdf_map": (C.c_int, [vp, dp, C.c_int]),
@@ -643,6 +644,11 @@ class GtopGroup:
     def update_sdf_map(self, pts):
         pts = _f64(pts).reshape(-1, 3)
         self._chk(self._L.gtop_group_update_sdf_map(self._h, _p(pts), pts.shape[0]))
+
+    def update_sdf_map_window(self, min_pos, max_pos, pts):
+        pts = _f64(pts).reshape(-1, 3)
+        mn, mx = _f64(min_pos).reshape(3), _f64(max_pos).reshape(3)
+        self._chk(self._L.gtop_group_update_sdf_map_window(self._h, _p(mn), _p(mx), _p(pts) if pts.size else None, pts.shape[0]))
 
     def set_problem(self, T, Df):
         Df = _f64(Df)

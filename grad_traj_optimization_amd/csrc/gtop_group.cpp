@@ -345,6 +345,27 @@ int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts) try {
   return sync_all(g);
 } GTOP_CATCH_STATUS(g)
 
+// the reference's local update (gtop_update_sdf_map_window) on every member: the replicated fields stay identical
+int gtop_group_update_sdf_map_window(gtop_group *g, const double min_pos[3], const double max_pos[3], const double *pts,
+                                     int npts) try {
+  if (!g) return GTOP_ERR_INVALID;
+  if (!min_pos || !max_pos || npts < 0 || (npts > 0 && !pts)) return gfail(g, GTOP_ERR_INVALID, "bad window / obstacle list");
+  const size_t need = (size_t)npts * 3;
+  for (Member &mb : g->mem) {
+    GHIP(g, hipSetDevice(mb.device));
+    if (need > mb.pts_cap) {
+      if (mb.pts) GHIP(g, hipFree(mb.pts));
+      mb.pts = nullptr;
+      mb.pts_cap = 0;
+      GHIP(g, hipMalloc(reinterpret_cast<void **>(&mb.pts), need * sizeof(double)));
+      mb.pts_cap = need;
+    }
+    if (need) GHIP(g, hipMemcpyAsync(mb.pts, pts, need * sizeof(double), hipMemcpyHostToDevice, mb.stream));
+    GCTX(g, mb, gtop_update_sdf_map_window_device(mb.ctx, min_pos, max_pos, mb.pts, npts, mb.stream));
+  }
+  return sync_all(g);
+} GTOP_CATCH_STATUS(g)
+
 int gtop_group_set_sdf(gtop_group *g, const double *dist_host, int nx, int ny, int nz, const double origin[3],
                        const double *map_size, double resolution) try {
   if (!g) return GTOP_ERR_INVALID;

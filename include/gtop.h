@@ -291,6 +291,8 @@ const char *gtop_group_gather_note(const gtop_group *g);
 int gtop_group_set_params(gtop_group *g, const gtop_params *p);
 int gtop_group_init_sdf_map(gtop_group *g, const double map_size[3], const double origin[3], double resolution);
 int gtop_group_update_sdf_map(gtop_group *g, const double *pts, int npts);
+int gtop_group_update_sdf_map_window(gtop_group *g, const double min_pos[3], const double max_pos[3], const double *pts,
+                                     int npts);   /* gtop_update_sdf_map_window on every member */
 int gtop_group_set_sdf(gtop_group *g, const double *dist_host, int nx, int ny, int nz, const double origin[3],
                        const double *map_size, double resolution);
 int gtop_group_set_problem(gtop_group *g, int B, int m, const double *segment_time, int time_stride,

@@ -27,6 +27,22 @@ int main(void) {
     oracle_set_occupancy(&S, occ, p, 1);   /* some of them out of the map on purpose */
   }
   oracle_esdf_build(&S, occ, dist);
+  {   /* the windowed update (sdf_map.cpp:28-53, :244-264, :310-368): boxes inside, across the map's border, the whole
+       * map, a sliver, an empty one (max below min) */
+    const double boxes[5][6] = {{-1.0, -1.0, 0.5, 0.8, 1.1, 2.0},   {-9.0, -9.0, -9.0, -1.5, 0.0, 1.0},
+                                {-99.0, -99.0, -99.0, 99.0, 99.0, 99.0}, {0.1, 0.1, 0.1, 0.15, 1.9, 3.1},
+                                {1.0, 1.0, 1.0, 0.5, 0.5, 0.5}};
+    for (int b = 0; b < 5; ++b) {
+      int lo[3], hi[3];
+      oracle_reset_window(&S, occ, dist, boxes[b], boxes[b] + 3);
+      for (int k = 0; k < 20; ++k) {
+        double p[3] = {origin[0] + urand(&seed) * 5.5 - 0.3, origin[1] + urand(&seed) * 4.6 - 0.3, urand(&seed) * 3.6 - 0.2};
+        oracle_set_occupancy(&S, occ, p, 1);
+      }
+      oracle_window_ids(&S, boxes[b], boxes[b] + 3, lo, hi);
+      oracle_esdf_build_window(&S, occ, dist, lo, hi);
+    }
+  }
   {   /* static field + moving boxes, in and out of the map, t < 0 and t >= 0 */
     double p0[6] = {origin[0] + 1.0, origin[1] + 1.0, 1.0, origin[0] + 3.0, origin[1] + 2.0, 2.0};
     double vel[6] = {0.3, -0.2, 0.0, -0.5, 0.1, 0.1}, scale[6] = {0.5, 0.7, 0.9, 1.1, 0.4, 0.6}, g3[3];

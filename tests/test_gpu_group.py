@@ -258,3 +258,29 @@ def test_more_than_one_distinct_device(gtop):
             for ci, gi in g.eval_resident(gather=2):
                 assert np.array_equal(ci, c_ref) and np.array_equal(gi, g_ref)
         g.close()
+
+
+def test_group_window_update_keeps_the_replicas_identical(scene, gtop, oracle_mod):
+    """gtop_group_update_sdf_map_window: the reference's local map update on every member — afterwards every member's
+    field is the oracle's, and a sharded evaluation equals the unsharded one on that field."""
+    mp, _ = scene
+    g = _group(gtop, mp, [0, 0])
+    sdf = oracle_mod.Sdf.from_map_size(mp.origin, mp.resolution, mp.map_size)
+    occ = sdf.build_from_points(mp.obstacle_points()).copy()
+    rng = np.random.default_rng(5)
+    a = mp.origin + 0.2 * mp.map_size
+    b_ = mp.origin + 0.7 * mp.map_size
+    pts = rng.uniform(a, b_, size=(60, 3))
+    g.update_sdf_map_window(a, b_, pts)
+    sdf.update_window(occ, a, b_, pts)
+    ref = gtop.GtopContext(device=0)
+    ref.set_sdf(sdf.dist, sdf.grid, mp.origin, mp.resolution, map_size=mp.map_size)
+    ref.set_params()
+    tr = problem.make_trajectories(300, 6, mp, seed=9)
+    ref.set_problem(tr.T, tr.Df)
+    c_ref, g_ref = ref.eval_batch(tr.x)
+    g.set_problem(tr.T, tr.Df)
+    c, gr = g.eval_batch(tr.x)
+    assert np.array_equal(c, c_ref) and np.array_equal(gr, g_ref)
+    g.close()
+    ref.close()
