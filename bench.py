@@ -724,7 +724,7 @@ def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
         lb, ub = gtop.GtopContext.default_bounds(batch.waypoints[:x.shape[0]])
         lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
         evals = 50
-        def run_optimizer():
+        def run_optimizer(x=x, Df=Df, T=T, lbt=lbt, ubt=ubt):
             """Host clock around one whole optimisation of the batch (launches + completion), the median of five runs
             after 40 ms of the same runs: after the seconds of host work before it the card needs 10-20 ms of load
             to reach its sustained clocks (tools/clock_ramp.py), and a single cold run read 5-30 % long."""
@@ -759,6 +759,23 @@ def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
             "batch": int(x.shape[0]), "evals_per_trajectory": evals, "seconds": dt_s,
             "trajectories_optimized_per_s": x.shape[0] / dt_s, **other,
             "median_cost_ratio_after_vs_before": float(torch.median(cmin / c0).item())}
+        if args.grid == 200 and args.segments == 6:
+            # the same driver on the large batch (the launch rule's other regime: for fp32 evaluations two trajectories
+            # per wavefront)
+            lbb, ubb = gtop.GtopContext.default_bounds(big.waypoints)
+            big_in = dict(x=torch.tensor(big.x, device=dev), Df=torch.tensor(big.Df.reshape(-1, 18), device=dev),
+                          T=torch.tensor(big.T, device=dev), lbt=torch.tensor(lbb, device=dev),
+                          ubt=torch.tensor(ubb, device=dev))
+            s64, cb64 = run_optimizer(**big_in)
+            ctx.set_optimizer_precision("f32")
+            s32, cb32 = run_optimizer(**big_in)
+            ctx.set_optimizer_precision("f64")
+            out["optimizer"]["large_batch"] = {
+                "batch": int(big.x.shape[0]), "evals_per_trajectory": evals, "seconds": s64,
+                "trajectories_optimized_per_s": big.x.shape[0] / s64, "seconds_with_fp32_evaluations": s32,
+                "trajectories_optimized_per_s_with_fp32_evaluations": big.x.shape[0] / s32,
+                "median_cost_ratio_fp32_evaluations_vs_fp64": float(torch.median(cb32 / cb64).item())}
+            del big_in
         if not args.no_cpu_baseline:
             # The same job on the host cores: per trajectory a serial CCSA-MMA around the callback, as the reference
             # runs NLopt's LD_MMA around costFunc (grad_traj_optimizer.cpp:137-195) — csrc/mma.hpp standing in for the

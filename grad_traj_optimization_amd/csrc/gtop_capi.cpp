@@ -271,7 +271,7 @@ void fill_args(const gtop_ctx *c, GtopKernelArgs<R> &a) {
 template <typename R>
 int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const void *d_Df,
                 const void *d_T, int t_stride, void *d_cost, void *d_grad, hipStream_t stream,
-                bool for_optimizer = false) {
+                const GtopEvalPlan *optimizer_plan = nullptr) {
   GtopKernelArgs<R> a;
   fill_args(c, a);
   a.sdf = sdf;
@@ -282,7 +282,8 @@ int launch_eval(gtop_ctx *c, const R *sdf, int B, int m, const void *d_x, const 
   a.grad = static_cast<R *>(d_grad);
   a.B = B; a.m = m; a.t_stride = t_stride;
   GtopEvalPlan plan;
-  if (!gtop_eval_plan(B, m, sizeof(R), c->spl, for_optimizer, &plan))
+  if (optimizer_plan) plan = *optimizer_plan;   // the geometry the optimizer's fused forms run: same bits
+  else if (!gtop_eval_plan(B, m, sizeof(R), c->spl, false, &plan))
     return fail(c, GTOP_ERR_INVALID, "this many segments cannot be served (ten lanes per segment: up to 6 segments; "
                                      "one wavefront's LDS: 227)");
   HIPCHK(c, gtop_launch_eval<R>(a, plan, c->prm.enable_dyn != 0, stream));
@@ -971,9 +972,15 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   st.x0_init = nullptr;
   st.out_x = st.out_minf = nullptr;
   st.out_code = st.out_nevals = nullptr;
-  // one trajectory per wavefront in every launch form; the whole loop in one launch by default (fusion mode 2)
+  // one geometry in every launch form; the whole loop in one launch by default (fusion mode 2)
   GtopEvalPlan plan;
-  if (!gtop_eval_plan(B, m, sizeof(double), c->spl, /*for_optimizer=*/true, &plan))
+  const bool f32 = c->opt_dtype == GTOP_F32;   // gtop_set_optimizer_precision: see below
+  const size_t eval_elem = f32 ? sizeof(float) : sizeof(double);
+  bool planned = gtop_eval_plan(B, m, eval_elem, c->spl, /*for_optimizer=*/true, &plan);
+  // (two trajectories per wavefront with the velocity / acceleration block compiled in: the fp32 loop would spill —
+  // enable_dyn keeps the loop at ten lanes per segment, one trajectory per wavefront)
+  if (planned && plan.nt == 2 && c->prm.enable_dyn != 0) planned = gtop_eval_plan(B, m, eval_elem, 3, true, &plan);
+  if (!planned)
     return fail(c, GTOP_ERR_INVALID, "optimize: this many segments cannot be served (ten lanes per segment: up to 6; "
                                      "one wavefront's LDS with the optimizer's state: 118)");
   const bool fused = c->fuse_mma != 0;
@@ -992,7 +999,6 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   const bool dyn = c->prm.enable_dyn != 0;
   // gtop_set_optimizer_precision(GTOP_F32): the same loop with its evaluations in fp32 on the fp32 field; the state,
   // the bounds, Df, T, the update and every result stay fp64 (the kernel converts as it reads its inputs from LDS)
-  const bool f32 = c->opt_dtype == GTOP_F32;
   GtopKernelArgs<float> a32;
   if (f32) {
     if (!fused) return fail(c, GTOP_ERR_INVALID, "optimize: fp32 evaluations need a fused launch form (gtop_set_optimizer_fusion 1 or 2)");
@@ -1030,7 +1036,7 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
       HIPCHK(c, launch_loop());
     } else {
       if ((rc = launch_eval<double>(c, c->rec64, B, m, st.xcur, d_Df, d_T, time_stride, c->mma_f, c->mma_g, s,
-                                    /*for_optimizer=*/true)))   // the geometry the fused modes run: same bits
+                                    &plan)))   // the geometry the fused modes run: same bits
         return rc;
       HIPCHK(c, gtop_launch_mma_update(st, B, (int)n, c->mma_f, c->mma_g, s));
     }

@@ -68,8 +68,8 @@ struct GtopEvalPlan {
   bool is_long;
   int nw;   // wavefronts per trajectory: 2 for 7 .. 12 segments at ten lanes per segment (small batches), else 1
 };
-// The launch rule.  pinned_spl: 0 = auto, 3 or 6; for_optimizer: one trajectory per wavefront (the optimizer loop and
-// the evaluations of its multi-launch forms).  false: the request cannot be served (m < 2, spl 3 with more than 6
+// The launch rule.  pinned_spl: 0 = auto, 3 or 6; for_optimizer: the optimizer loop and the evaluations of its
+// multi-launch forms (the same rule with the loop's own switch point to two trajectories per wavefront).  false: the request cannot be served (m < 2, spl 3 with more than 6
 // segments, more segments than one wavefront's LDS holds — 227, in the optimizer loop 118).
 bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimizer, GtopEvalPlan *plan);
 // dyn: enable_dyn (the kernel applies it at step 2 only, as the commented-out block would)

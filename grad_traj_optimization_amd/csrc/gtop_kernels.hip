@@ -701,7 +701,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
                       int arg_nz, const GtopKernelArgs<R> arg_rest, const GtopWaveConsts<R> K, const MM st,
                       const GtopSetupConsts<R> KD) {
   constexpr bool MMA = !std::is_same<MM, GtopNoMma>::value;
-  static_assert(!MMA || NT == 1, "the optimizer loop: one trajectory per wavefront");
+  static_assert(!MMA || NT == 1 || (SPL == 6 && !LONG), "the optimizer loop: one trajectory per wavefront, or two at five lanes per segment");
   // the optimizer's state, bounds, Df and T are fp64 whatever R is: with R = float only the evaluation runs in fp32
   // (its inputs converted as they are read from LDS, its cost and gradient widened for the update)
   using In = typename std::conditional<MMA, double, R>::type;
@@ -712,7 +712,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   constexpr int LPS = kSamples / SPL;   // lanes per segment
   constexpr int SPW = 64 / LPS;         // segment slots per wavefront
   constexpr int kStride = NW == 2 ? ((2 * LPS * SPW) | 1) : red_stride(SPL);   // (two wavefronts: 120 busy lanes)
-  constexpr int kMVc = SPL == 6 ? 128 : 64;   // rows of the optimizer loop's LDS vectors: n <= 45 resp. 99 variables
+  constexpr int kMVc = (SPL == 6 && NT == 1) ? 128 : 64;   // rows of the optimizer loop's LDS vectors: n <= 45 resp. 99 variables
   static_assert(SPL == 3 || SPL == 6, "10 or 5 lanes per segment");
   static_assert(SPL == 3 || MINW >= 3, "six samples per lane: one (pair) at a time only");
   static_assert(NT == 1 || NT == 2, "one or two trajectories per wavefront");
@@ -766,51 +766,60 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // the tile and the gradient rows; n <= 45 < 64, lane j owns entry j) and the scalars in registers; global memory
   // sees it once, at the end.  With the state in global memory every pass paid five dependent round trips for it — 7 us per pass,
   // of which the evaluation is 2.5.
-  [[maybe_unused]] double *mv = nullptr;   // [8][kMV]: x, xcur, xprev, xprevprev, dfdx, sigma, lb, ub; then Df, T
-  [[maybe_unused]] GtopMmaVecs mvecs = {};
-  [[maybe_unused]] GtopMmaScalars msc = {};
-  [[maybe_unused]] bool mma_live = false;
+  // NT = 2 (up to 6 segments each, large batches): the wavefront keeps BOTH its trajectories' states — two blocks of
+  // kState doubles — and runs the update twice per pass, once per trajectory, every lane serving the trajectory in turn;
+  // a trajectory that has stopped is still evaluated (its lanes cannot leave) but no longer updated.
+  [[maybe_unused]] double *mv = nullptr;   // per trajectory [8][kMV]: x, xcur, xprev, xprevprev, dfdx, sigma, lb, ub; then Df, T
+  [[maybe_unused]] const int kState = LONG ? 0 : 8 * kMVc + 32;   // doubles per trajectory (LONG: one trajectory)
+  [[maybe_unused]] GtopMmaVecs mvecs[NT] = {};
+  [[maybe_unused]] GtopMmaScalars msc[NT] = {};
+  [[maybe_unused]] bool mma_live[NT] = {};
   if constexpr (MMA) {
     mv = reinterpret_cast<double *>(tile) + kTileRows * tstride + (LONG ? kMV : 128);
     // (the evaluation reads its inputs from here too — the trial point, and Df and T staged once behind the
     // vectors — so a pass has no global load but the distance-field corners, and no global store at all)
-    mvecs = GtopMmaVecs{mv, mv + kMV, mv + 2 * kMV, mv + 3 * kMV, mv + 4 * kMV, mv + 5 * kMV, mv + 6 * kMV, mv + 7 * kMV,
-                        mv + kMV};
-    mma_live = grp_ok;
-    if (mma_live) {
-      const size_t o = (size_t)b0 * n;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+    double *mvt = mv + t * kState;
+    const int bt = b0 + t;
+    mvecs[t] = GtopMmaVecs{mvt, mvt + kMV, mvt + 2 * kMV, mvt + 3 * kMV, mvt + 4 * kMV, mvt + 5 * kMV, mvt + 6 * kMV,
+                           mvt + 7 * kMV, mvt + kMV};
+    mma_live[t] = grp_ok & (bt < a.B);
+    if (mma_live[t]) {
+      const size_t o = (size_t)bt * n;
       const double *Df64 = reinterpret_cast<const double *>(a.Df), *T64 = reinterpret_cast<const double *>(a.T);
-      if (lane < 18) mv[8 * kMV + lane] = Df64[(size_t)b0 * 18 + lane];
+      if (lane < 18) mvt[8 * kMV + lane] = Df64[(size_t)bt * 18 + lane];
       if constexpr (LONG) {
-        for (int j = lane; j < m; j += 64) mv[8 * kMV + 18 + j] = T64[(size_t)b0 * a.t_stride + j];
+        for (int j = lane; j < m; j += 64) mvt[8 * kMV + 18 + j] = T64[(size_t)bt * a.t_stride + j];
       } else {
-        if (lane < m) mv[8 * kMV + 18 + lane] = T64[(size_t)b0 * a.t_stride + lane];
+        if (lane < m) mvt[8 * kMV + 18 + lane] = T64[(size_t)bt * a.t_stride + lane];
       }
       if (st.x0_init) {   // (uniform) a fresh problem: mma_init_kernel's arithmetic, straight into LDS
-        msc = GtopMmaScalars{1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0};
+        msc[t] = GtopMmaScalars{1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0};
         for (int j = lane; j < n; j += 64) {
           const double lo = st.lb[o + j], hi = st.ub[o + j];
           double v = st.x0_init[o + j];
           v = v < lo ? lo : (v > hi ? hi : v);   // nlopt clamps the start into the box
-          mv[j] = v; mv[kMV + j] = v; mv[2 * kMV + j] = v; mv[3 * kMV + j] = v;
-          mv[4 * kMV + j] = 0.0;
-          mv[5 * kMV + j] = (isinf(lo) || isinf(hi)) ? 1.0 : 0.5 * (hi - lo);
-          mv[6 * kMV + j] = lo;
-          mv[7 * kMV + j] = hi;
+          mvt[j] = v; mvt[kMV + j] = v; mvt[2 * kMV + j] = v; mvt[3 * kMV + j] = v;
+          mvt[4 * kMV + j] = 0.0;
+          mvt[5 * kMV + j] = (isinf(lo) || isinf(hi)) ? 1.0 : 0.5 * (hi - lo);
+          mvt[6 * kMV + j] = lo;
+          mvt[7 * kMV + j] = hi;
         }
       } else {
-      msc = gtop_mma_load_scalars(st, b0);
+      msc[t] = gtop_mma_load_scalars(st, bt);
       for (int j = lane; j < n; j += 64) {
-        mv[j] = st.x[o + j];
-        mv[kMV + j] = st.xcur[o + j];
-        mv[2 * kMV + j] = st.xprev[o + j];
-        mv[3 * kMV + j] = st.xprevprev[o + j];
-        mv[4 * kMV + j] = st.dfdx[o + j];
-        mv[5 * kMV + j] = st.sigma[o + j];
-        mv[6 * kMV + j] = st.lb[o + j];
-        mv[7 * kMV + j] = st.ub[o + j];
+        mvt[j] = st.x[o + j];
+        mvt[kMV + j] = st.xcur[o + j];
+        mvt[2 * kMV + j] = st.xprev[o + j];
+        mvt[3 * kMV + j] = st.xprevprev[o + j];
+        mvt[4 * kMV + j] = st.dfdx[o + j];
+        mvt[5 * kMV + j] = st.sigma[o + j];
+        mvt[6 * kMV + j] = st.lb[o + j];
+        mvt[7 * kMV + j] = st.ub[o + j];
       }
       }
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // staged by some lanes, read by others of this wavefront
     __builtin_amdgcn_wave_barrier();
@@ -820,9 +829,14 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   if constexpr (MMA) {
     // stop rules (mma.hpp:35-39; set_maxtime, :144-148), wave-uniform: a trajectory that has stopped (ftol / xtol in the
     // update) leaves the loop; past the wall-clock limit a running one stops where it is, after at least one evaluation
-    if (!mma_live || msc.state >= 3) break;
+    bool running = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) running |= mma_live[t] && msc[t].state < 3;
+    if (!running) break;
     if (st.max_ticks > 0 && pass > 0 && (long long)(wall_clock64() - t_launch) > st.max_ticks) {
-      msc.state = GTOP_MMA_MAXTIME_REACHED;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (mma_live[t] && msc[t].state < 3) msc[t].state = GTOP_MMA_MAXTIME_REACHED;
       break;
     }
   }
@@ -842,9 +856,10 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // derivative vector layout (src/qp_generator.cpp:363-387): start | end | waypoint 1 | ... | waypoint m-1
   const In *xb, *dfb, *Tb;
   if constexpr (MMA) {
-    xb = mv + kMV;
-    dfb = mv + 8 * kMV;
-    Tb = mv + 8 * kMV + 18;
+    const double *mvl = mv + tl * kState;   // this lane's trajectory
+    xb = mvl + kMV;
+    dfb = mvl + 8 * kMV;
+    Tb = mvl + 8 * kMV + 18;
   } else {
     xb = xsrc + (size_t)b0 * n + tl * n;      // this lane's trajectory (b0: wave-uniform)
     dfb = a.Df + (size_t)b0 * 18 + tl * 18;
@@ -1329,7 +1344,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     if constexpr (MMA) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
       __builtin_amdgcn_wave_barrier();
-      gtop_mma_update_core(st, mvecs, msc, n, lane, (double)ctot, static_cast<const R *>(gl));
+      gtop_mma_update_core(st, mvecs[0], msc[0], n, lane, (double)ctot, static_cast<const R *>(gl));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is rewritten by the next evaluation
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -1354,7 +1369,21 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     cpart += gtop_dpp_move<0x111>(cpart);   // row_shr:1
     cpart += gtop_dpp_move<0x112>(cpart);   // row_shr:2
     cpart += gtop_dpp_move<0x114>(cpart);   // row_shr:4  -> lane 55 holds lanes 48..55, lane 63 lanes 56..63
-    if constexpr (NT == 2) {
+    if constexpr (NT == 2 && MMA) {
+      // f(xcur) of each trajectory to every lane (lane 55: the first's, lane 63: the second's), then the two updates
+      const unsigned long long u = __builtin_bit_cast(unsigned long long, (double)(cpart + (R)1e-3));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 55 + 8 * t);
+        const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 55 + 8 * t);
+        const double fcur = __builtin_bit_cast(double, ((unsigned long long)hi32 << 32) | lo32);
+        if (mma_live[t]) gtop_mma_update_core(st, mvecs[t], msc[t], n, lane, fcur, static_cast<const R *>(gl) + t * n);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is rewritten by the next evaluation
+      __builtin_amdgcn_wave_barrier();
+    } else if constexpr (NT == 2) {
       if (grp_ok & (lane == 55)) a.cost[b0] = cpart + (R)1e-3;
       if (grp_ok & (lane == 63) & (b0 + 1 < a.B)) a.cost[b0 + 1] = cpart + (R)1e-3;
     } else if constexpr (NW * SPW > 8 && !MMA) {
@@ -1370,7 +1399,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
       const double fcur = __builtin_bit_cast(double, ((unsigned long long)hi32 << 32) | lo32);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // gl is complete (this wavefront's own LDS writes)
       __builtin_amdgcn_wave_barrier();
-      gtop_mma_update_core(st, mvecs, msc, n, lane, fcur, static_cast<const R *>(gl));
+      gtop_mma_update_core(st, mvecs[0], msc[0], n, lane, fcur, static_cast<const R *>(gl));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is rewritten by the next evaluation
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -1385,27 +1414,32 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
 #endif
   }   // pass
   if constexpr (MMA) {
-    if (mma_live) {   // the state goes home
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const size_t o = (size_t)b0 * n;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+    if (mma_live[t]) {   // the state goes home
+      const double *mvt = mv + t * kState;
+      const int bt = b0 + t;
+      const size_t o = (size_t)bt * n;
       for (int j = lane; j < n; j += 64) {
-        st.x[o + j] = mv[j];
-        st.xcur[o + j] = mv[kMV + j];
-        st.xprev[o + j] = mv[2 * kMV + j];
-        st.xprevprev[o + j] = mv[3 * kMV + j];
-        st.dfdx[o + j] = mv[4 * kMV + j];
-        st.sigma[o + j] = mv[5 * kMV + j];
+        st.x[o + j] = mvt[j];
+        st.xcur[o + j] = mvt[kMV + j];
+        st.xprev[o + j] = mvt[2 * kMV + j];
+        st.xprevprev[o + j] = mvt[3 * kMV + j];
+        st.dfdx[o + j] = mvt[4 * kMV + j];
+        st.sigma[o + j] = mvt[5 * kMV + j];
       }
-      if (lane == 0) gtop_mma_store_scalars(st, b0, msc);
+      if (lane == 0) gtop_mma_store_scalars(st, bt, msc[t]);
       // the results, where the caller wants them (otherwise: copies + mma_finish_kernel after this launch)
       if (st.out_x)
-        for (int j = lane; j < n; j += 64) st.out_x[o + j] = mv[j];
+        for (int j = lane; j < n; j += 64) st.out_x[o + j] = mvt[j];
       if (lane == 0) {
-        if (st.out_minf) st.out_minf[b0] = msc.minf;
-        if (st.out_code) st.out_code[b0] = msc.state >= 3 ? msc.state : GTOP_MMA_MAXEVAL_REACHED;
-        if (st.out_nevals) st.out_nevals[b0] = msc.nevals;
+        if (st.out_minf) st.out_minf[bt] = msc[t].minf;
+        if (st.out_code) st.out_code[bt] = msc[t].state >= 3 ? msc[t].state : GTOP_MMA_MAXEVAL_REACHED;
+        if (st.out_nevals) st.out_nevals[bt] = msc[t].nevals;
       }
+    }
     }
   }
 }
@@ -1424,6 +1458,17 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 #ifndef GTOP_TWO_PER_WAVE_F32_FROM
 #define GTOP_TWO_PER_WAVE_F32_FROM 2048
 #endif
+// The optimizer loop with two trajectories per wavefront (both states in LDS, the update once per trajectory) needs the
+// two-wavefront register budget, where the plain two-per-wavefront body runs three wavefronts per SIMD.  Measured per
+// pass of the loop (one box, us, one | two per wavefront): fp32 evaluations B = 2 048 5.0 | 5.2, 3 072 9.0 | 7.5,
+// 4 096 11.2 | 7.6, 8 192 19.2 | 14.5, 16 384 35.8 | 28.0 — from 3 072; fp64 4 096 9.6 | 9.8, 8 192 18.4 | 18.5,
+// 16 384 36.2 | 35.3: no gain, the fp64 loop stays at one per wavefront unless six samples per lane are pinned.
+#ifndef GTOP_OPT_TWO_PER_WAVE_F32_FROM
+#define GTOP_OPT_TWO_PER_WAVE_F32_FROM 3072
+#endif
+#ifndef GTOP_OPT_TWO_PER_WAVE_F64_FROM
+#define GTOP_OPT_TWO_PER_WAVE_F64_FROM (1 << 30)
+#endif
 #ifndef GTOP_TWO_WAVES_UP_TO
 #define GTOP_TWO_WAVES_UP_TO 1024   // trajectories of 7 .. 12 segments: two wavefronts each up to this batch (2 048 wavefronts)
 #endif
@@ -1435,9 +1480,9 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 // state (eight vectors, Df, T).  Mirrors the pointer arithmetic of gtop_eval_wave_kernel.
 static size_t wave_lds_bytes(const GtopEvalPlan &p, int m, size_t elem, bool mma) {
   if (!p.is_long) {
-    const int kmv = p.spl == 6 ? 128 : 64;
+    const int kmv = (p.spl == 6 && p.nt == 1) ? 128 : 64;
     const int stride = p.nw == 2 ? 121 : red_stride(p.spl);
-    return (size_t)(kRedVals * stride + 128 + (mma ? 8 * kmv + 32 : 0)) * elem;
+    return (size_t)(kRedVals * stride + 128 + (mma ? p.nt * (8 * kmv + 32) : 0)) * elem;
   }
   const int n = 9 * (m - 1), kmv = (n + 63) & ~63, tstride = ((kSamples / 6) * m) | 1;
   return ((size_t)18 * tstride + (mma ? (size_t)9 * kmv + 18 + m + 8 : 0)) * elem;
@@ -1447,7 +1492,7 @@ static size_t wave_lds_bytes(const GtopEvalPlan &p, int m, size_t elem, bool mma
 // trajectory, up to 12 288 trajectories in fp64 and 8 192 in fp32, where two trajectories per wavefront at five lanes
 // per segment take over (fp32: packed sample pairs).  7 .. 12 segments: five lanes per segment, one
 // trajectory per wavefront.  Past 12: the same wavefront walks the segments 12 at a time (LONG).  The optimizer loop
-// always has one trajectory per wavefront.  pinned_spl = 3 or 6 overrides the lanes-per-segment choice where it can
+// follows the same rule with its own switch points (elem: the precision of its evaluations).  pinned_spl = 3 or 6 overrides the lanes-per-segment choice where it can
 // be honoured (3: up to 6 segments).
 bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimizer, GtopEvalPlan *plan) {
   if (m < 2 || (pinned_spl != 0 && pinned_spl != 3 && pinned_spl != 6)) return false;
@@ -1459,7 +1504,11 @@ bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimize
   // together (one box, us, ten lanes | five lanes per segment): fp64 B = 3 072 8.0 | 9.1, 4 096 10.4 | 9.7, 8 192 18.6 |
   // 16.9, 16 384 36.9 | 30.7 — from 4 096 (round 3: 12 288); fp32, packed pairs: 2 048 5.25 | 4.90, 4 096 8.3 | 7.4,
   // 16 384 27.0 | 23.5 — from 2 048 (round 3: 8 192))
-  if (m <= 6) p.spl = pinned_spl ? pinned_spl : ((B >= (elem == 4 ? GTOP_TWO_PER_WAVE_F32_FROM : GTOP_TWO_PER_WAVE_F64_FROM) && !for_optimizer) ? 6 : 3);
+  if (m <= 6) {
+    const int from = for_optimizer ? (elem == 4 ? GTOP_OPT_TWO_PER_WAVE_F32_FROM : GTOP_OPT_TWO_PER_WAVE_F64_FROM)
+                                   : (elem == 4 ? GTOP_TWO_PER_WAVE_F32_FROM : GTOP_TWO_PER_WAVE_F64_FROM);
+    p.spl = pinned_spl ? pinned_spl : (B >= from ? 6 : 3);
+  }
   else if (m <= 12 && !for_optimizer && pinned_spl != 6 &&
            (pinned_spl == 3 || B <= (elem == 4 ? GTOP_TWO_WAVES_UP_TO / 2 : GTOP_TWO_WAVES_UP_TO))) {
     // 7 .. 12 segments, a batch that leaves SIMDs idle with one wavefront per trajectory: two wavefronts per
@@ -1471,8 +1520,9 @@ bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimize
   } else if (pinned_spl == 3) return false;   // ten lanes per segment: six segments fill a wavefront, twelve fill two
   else p.spl = 6;
   p.is_long = m > 12;
-  p.nt = (p.spl == 6 && 2 * m <= 12 && !for_optimizer) ? 2 : 1;
-  if (wave_lds_bytes(p, m, elem, for_optimizer) > 160u * 1024u) return false;   // ~200 segments
+  p.nt = (p.spl == 6 && 2 * m <= 12) ? 2 : 1;
+  // (the optimizer's state and tile are fp64 whatever precision its evaluations run in)
+  if (wave_lds_bytes(p, m, for_optimizer ? sizeof(double) : elem, for_optimizer) > 160u * 1024u) return false;   // ~200 segments
   *plan = p;
   return true;
 }
@@ -1507,8 +1557,14 @@ static WaveKernelFn<R, MM> pick_geometry(const GtopEvalPlan &p, int B, bool coll
     }
     return pick_body<R, WIDE, 3, 1, 2, MM, false>(colli, dyn);
   }
-  if constexpr (!MMA) {
-    if (p.nt == 2) return pick_body<R, WIDE, 6, 2, 3, MM, false>(colli, dyn);
+  if (p.nt == 2) {
+    if constexpr (MMA) {   // (the loop never takes two trajectories per wavefront with DYN: gtop_optimize_device_ex)
+      if (dyn) return nullptr;
+      return colli ? gtop_eval_wave_kernel<R, WIDE, 6, 2, true, 3, MM, false, false, 1>
+                   : gtop_eval_wave_kernel<R, WIDE, 6, 2, false, 3, MM, false, false, 1>;
+    } else {
+      return pick_body<R, WIDE, 6, 2, 3, MM, false>(colli, dyn);
+    }
   }
   return pick_body<R, WIDE, 6, 1, 3, MM, false>(colli, dyn);
 }
@@ -1533,6 +1589,7 @@ static hipError_t launch_wave(const GtopKernelArgs<R> &args, const MM &st, const
   } else {
     kern = wide ? pick_geometry<R, true, MM>(plan, wa.B, colli, dyn) : pick_geometry<R, false, MM>(plan, wa.B, colli, dyn);
   }
+  if (!kern) return hipErrorInvalidValue;
   const size_t smem = wave_lds_bytes(plan, wa.m, MMA ? sizeof(double) : sizeof(R), MMA);   // (the optimizer's state is fp64)
   if (smem > 160u * 1024u) return hipErrorInvalidValue;
   if (smem > 64u * 1024u) {
@@ -1571,14 +1628,14 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &p
 // the optimizer loop: st.iters evaluations at st.xcur, each followed by the CCSA-MMA update, in one launch (fp64)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
                                 bool dyn, hipStream_t stream) {
-  if (plan.nt != 1 || plan.nw != 1) return hipErrorInvalidValue;
+  if (plan.nw != 1 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
   return launch_wave<double, GtopMmaState>(args, st, plan, dyn, stream);
 }
 // the same loop with the evaluations in fp32 on the fp32 field: args.Df / args.T still point at fp64 rows (the state,
 // the bounds, the update and the results are fp64; see the kernel's `In`), args.x / cost / grad are not read
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<float> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
                                 bool dyn, hipStream_t stream) {
-  if (plan.nt != 1 || plan.nw != 1) return hipErrorInvalidValue;
+  if (plan.nw != 1 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
   return launch_wave<float, GtopMmaState>(args, st, plan, dyn, stream);
 }
 

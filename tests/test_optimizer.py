@@ -184,12 +184,14 @@ def test_optimize_device_api_and_determinism(scene, gtop):
     assert (c1 <= c0).all() and (c1 < 0.5 * c0).float().mean() > 0.9
 
 
-@pytest.mark.parametrize("B,m", [(64, 6), (5000, 6), (300, 12), (100, 17)])
-def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m):
+@pytest.mark.parametrize("B,m,pin", [(64, 6, 3), (5000, 6, 0), (4097, 6, 6), (33, 4, 6), (300, 12, 0), (100, 17, 0)])
+def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m, pin):
     """Three ways to run the same loop — the whole loop in one launch (default), the MMA
     update as the evaluation kernel's epilogue with one launch per iteration, and the
     two-launch form — do the same arithmetic: bit-identical results at the same launch
-    geometry (pinned here: left to itself the one-launch form picks its own)."""
+    geometry.  pin 6 with up to 6 segments: TWO trajectories per wavefront, both states in LDS, the update run once per
+    trajectory (odd batches: a last wavefront with one) — what the launch rule picks by itself for fp32 evaluations
+    from 3 072 trajectories (test_optimizer_with_fp32_evaluations)."""
     import torch
     mp, ctx, sdf = scene
     b = problem.make_trajectories(B, m, mp, seed=900 + m)
@@ -200,7 +202,7 @@ def test_fused_optimizer_step_equals_separate_launches(scene, gtop, B, m):
     lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
     ctx.set_params()
     res = []
-    ctx.set_launch_geometry(0, 0 if m > 6 else (3 if B < 4096 else 6))
+    ctx.set_launch_geometry(0, pin)
     for mode in (2, 1, 0):
         ctx.set_optimizer_fusion(mode)
         x = torch.tensor(b.x, device=dev)
@@ -253,35 +255,41 @@ def test_device_stop_rules_follow_the_serial_algorithm(scene, oracle_mod, gtop, 
     ctx.set_problem(b.T, b.Df)
     # (a) full cost: same decisions whatever the launch form (one body pinned: same bits)
     ctx.set_params()
-    res = {}
-    ctx.set_launch_geometry(0, 3)
-    for mode in (2, 1, 0):               # whole loop in one launch; one launch per iteration; separate update launch
-        ctx.set_optimizer_fusion(mode)
-        res[mode] = ctx.optimize_batch_ex(b.x, lb, ub, cap, **rule)
-    ctx.set_optimizer_fusion(2)
-    ctx.set_launch_geometry(0, 0)
-    for mode in (1, 0):
-        for a, r in zip(res[mode], res[2]):
-            assert np.array_equal(a, r)
-    assert (res[2][3] != 5).sum() >= B // 2 and res[2][2][res[2][3] != 5].max() < cap      # the rules did fire
+    for pin in (3, 6):                       # (6: two trajectories per wavefront, each stopping on its own)
+        res = {}
+        ctx.set_launch_geometry(0, pin)
+        for mode in (2, 1, 0):               # whole loop in one launch; one launch per iteration; separate update launch
+            ctx.set_optimizer_fusion(mode)
+            res[mode] = ctx.optimize_batch_ex(b.x, lb, ub, cap, **rule)
+        ctx.set_optimizer_fusion(2)
+        ctx.set_launch_geometry(0, 0)
+        for mode in (1, 0):
+            for a, r in zip(res[mode], res[2]):
+                assert np.array_equal(a, r)
+        assert (res[2][3] != 5).sum() >= B // 2 and res[2][2][res[2][3] != 5].max() < cap      # the rules did fire
+        if pin == 6:
+            assert (res[2][2][0::2] != res[2][2][1::2]).any()      # wavefronts whose two trajectories part ways
     # (b) jerk term alone against the serial twin
     kw = dict(wc=0.0)
-    ctx.set_params(**kw)
-    try:
-        xs, costs, nev, code = ctx.optimize_batch_ex(b.x, lb, ub, cap, **rule)
-    finally:
-        ctx.set_params()
     prm = oracle_mod.make_params(**kw)
-    for i in range(B):
-        gen = oracle_mod.generator(b.T[i])
+    for pin in (0, 6):
+        ctx.set_params(**kw)
+        ctx.set_launch_geometry(0, pin)
+        try:
+            xs, costs, nev, code = ctx.optimize_batch_ex(b.x, lb, ub, cap, **rule)
+        finally:
+            ctx.set_params()
+            ctx.set_launch_geometry(0, 0)
+        for i in range(B):
+            gen = oracle_mod.generator(b.T[i])
 
-        def f(x, i=i, gen=gen):
-            return oracle_mod.cost_grad(b.T[i], b.Df[i], x, sdf, prm, L=gen["L"], R=gen["R"])
-        x_ref, f_ref, _, nev_ref, code_ref = mma_serial(f, b.x[i], lb[i], ub[i], cap, full=True, **rule)
-        assert (nev[i], code[i]) == (nev_ref, code_ref), (i, nev[i], code[i], nev_ref, code_ref)
-        assert abs(costs[i] - f_ref) <= 1e-4 * abs(f_ref)          # (up to 80 iterations of rounding differences)
-        assert np.max(np.abs(xs[i] - x_ref)) <= 1e-4 * max(1.0, np.max(np.abs(x_ref)))
-    assert (code != 5).sum() >= B - 2 and nev[code != 5].max() < cap
+            def f(x, i=i, gen=gen):
+                return oracle_mod.cost_grad(b.T[i], b.Df[i], x, sdf, prm, L=gen["L"], R=gen["R"])
+            x_ref, f_ref, _, nev_ref, code_ref = mma_serial(f, b.x[i], lb[i], ub[i], cap, full=True, **rule)
+            assert (nev[i], code[i]) == (nev_ref, code_ref), (pin, i, nev[i], code[i], nev_ref, code_ref)
+            assert abs(costs[i] - f_ref) <= 1e-4 * abs(f_ref)          # (up to 80 iterations of rounding differences)
+            assert np.max(np.abs(xs[i] - x_ref)) <= 1e-4 * max(1.0, np.max(np.abs(x_ref)))
+        assert (code != 5).sum() >= B - 2 and nev[code != 5].max() < cap
     # no rule set: the cap is the only stop, as before
     x0, c0, n0, k0 = ctx.optimize_batch_ex(b.x, lb, ub, 12)
     x1, c1 = ctx.optimize_batch(b.x, lb, ub, 12)
@@ -301,14 +309,15 @@ def test_device_wall_clock_stop(scene, gtop):
     T = torch.tensor(b.T, device=dev)
     lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
     ctx.set_params()
-    x, c, nev, code = ctx.optimize_device_ex(torch.tensor(b.x, device=dev), Df, T, lbt, ubt, 400, maxtime=20e-6)
-    torch.cuda.synchronize()
-    assert (code == 6).all() and (nev >= 1).all() and (nev < 400).all()
-    ctx.set_launch_geometry(0, 3)
-    chk, _ = ctx.eval_device(x, Df, T)
-    torch.cuda.synchronize()
-    ctx.set_launch_geometry(0, 0)
-    assert torch.max(torch.abs(chk - c) / c).item() <= 1e-12       # min_cost is the cost of the returned point
+    for pin in (3, 6):                       # (6: two trajectories per wavefront)
+        ctx.set_launch_geometry(0, pin)
+        x, c, nev, code = ctx.optimize_device_ex(torch.tensor(b.x, device=dev), Df, T, lbt, ubt, 400, maxtime=20e-6)
+        torch.cuda.synchronize()
+        assert (code == 6).all() and (nev >= 1).all() and (nev < 400).all()
+        chk, _ = ctx.eval_device(x, Df, T)
+        torch.cuda.synchronize()
+        ctx.set_launch_geometry(0, 0)
+        assert torch.max(torch.abs(chk - c) / c).item() <= 1e-12       # min_cost is the cost of the returned point
     xa, ca, na, ka = ctx.optimize_device_ex(torch.tensor(b.x, device=dev), Df, T, lbt, ubt, 15, maxtime=10.0)
     xb, cb = ctx.optimize_device(torch.tensor(b.x, device=dev), Df, T, lbt, ubt, 15)
     torch.cuda.synchronize()
@@ -390,10 +399,12 @@ def test_stop_rule_precedence_follows_nlopt(scene, oracle_mod, gtop):
         ctx.set_params()
 
 
-@pytest.mark.parametrize("B,m,fusion", [(300, 6, 2), (300, 6, 1), (200, 9, 2), (64, 17, 2), (4000, 6, 2)])
+@pytest.mark.parametrize("B,m,fusion", [(300, 6, 2), (300, 6, 1), (200, 9, 2), (64, 17, 2), (4000, 6, 2), (4201, 6, 2),
+                                          (4201, 5, 1)])
 def test_optimizer_with_fp32_evaluations(scene, oracle_mod, gtop, B, m, fusion):
     """gtop_set_optimizer_precision(GTOP_F32): the loop's evaluations on the fp32 field in the fp32 bodies (up to 6
-    segments, 7 .. 12 in packed pairs, the chunked body), its state, update and results fp64.  The objective it
+    segments — from 3 072 trajectories two per wavefront —, 7 .. 12 in packed pairs, the chunked body), its state,
+    update and results fp64.  The objective it
     minimises is the fp32 one, so its road may part from the fp64 loop's at a decision inside fp32's noise; what must
     hold: the returned cost IS the callback's value at the returned point (to the fp32 bound), the point is inside
     its bounds and no worse than the start, evaluation counts and codes as the fp64 loop's, and the batch as a whole

@@ -26,7 +26,7 @@ for B in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384]:
     T = torch.tensor(b.T, device=dev)
     lbt, ubt = torch.tensor(lb, device=dev), torch.tensor(ub, device=dev)
     x0 = torch.tensor(b.x, device=dev)
-    for spl, mode, prec in ((0, 2, "f64"), (0, 2, "f64"), (0, 2, "f32"), (0, 1, "f64"), (0, 1, "f32"), (6, 2, "f64")):
+    for spl, mode, prec in ((3, 2, "f64"), (3, 2, "f64"), (6, 2, "f64"), (3, 2, "f32"), (6, 2, "f32"), (0, 1, "f64"), (0, 1, "f32")):
         if True:
             ctx.set_launch_geometry(0, spl)
             ctx.set_optimizer_fusion(mode)
