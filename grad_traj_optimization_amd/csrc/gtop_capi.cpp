@@ -495,6 +495,12 @@ static int update_window_on_stream(gtop_ctx *c, const double min_pos[3], const d
   if ((rc = ensure(c, &c->occ, &c->cap_occ, nvox))) return rc;
   if ((rc = ensure(c, &c->tmp1, &c->cap_tmp1, nvox))) return rc;
   if ((rc = ensure(c, &c->tmp2, &c->cap_tmp2, nvox))) return rc;
+  // (scratch for the compact path, sized for the whole grid whatever this window is: the first window update of a map
+  // allocates, later ones of any size do not — capturable, and no implicit device synchronisation from a reallocation
+  // between two enqueued updates)
+  if ((rc = ensure(c, &c->rows, &c->cap_rows, gtop_esdf_rows_ints(g)))) return rc;
+  if ((rc = ensure(c, &c->win_occ, &c->cap_win_occ, nvox))) return rc;
+  if ((rc = ensure(c, &c->win_dist, &c->cap_win_dist, nvox))) return rc;
   const bool empty = hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2];
   const bool whole = !empty && lo[0] == 0 && lo[1] == 0 && lo[2] == 0 && hi[0] == g.nx - 1 && hi[1] == g.ny - 1 && hi[2] == g.nz - 1;
   if (whole)   // the window is the map: the whole-grid builder (same results: every distance is 10000 after the reset)
@@ -510,10 +516,6 @@ static int update_window_on_stream(gtop_ctx *c, const double min_pos[3], const d
   GtopGrid sub = g;
   sub.nx = wx; sub.ny = wy; sub.nz = wz;
   if (wx >= 12 && wy >= 12 && wz >= 3 && gtop_esdf_supported(sub)) {
-    const size_t nsub = (size_t)wx * wy * wz;
-    if ((rc = ensure(c, &c->rows, &c->cap_rows, gtop_esdf_rows_ints(g)))) return rc;   // (sized for the whole grid: covers any window)
-    if ((rc = ensure(c, &c->win_occ, &c->cap_win_occ, nsub))) return rc;
-    if ((rc = ensure(c, &c->win_dist, &c->cap_win_dist, nsub))) return rc;
     HIPCHK(c, gtop_launch_esdf_window_gather(g, lo, hi, c->occ, c->win_occ, s));
     HIPCHK(c, gtop_launch_esdf_build(sub, c->win_occ, c->tmp1, c->tmp2, c->rows, c->win_dist, nullptr, s));
     HIPCHK(c, gtop_launch_esdf_window_scatter(g, lo, hi, c->win_dist, c->sdf64, s));

@@ -140,7 +140,10 @@ int gtop_update_sdf_map_device(gtop_ctx *ctx, const void *d_obstacle_pts, int np
  * min(res*sqrt(val), 10000).  Only the corner records of the box are rebuilt, so
  * the cost follows the box, not the map.  A box that covers the whole map takes
  * the whole-grid builder (same results).  Occupancy persists between calls, as in
- * the reference.  The _device form takes the points in HBM and only enqueues. */
+ * the reference.  The _device form takes the points in HBM and only enqueues;
+ * the first window update after gtop_init_sdf_map allocates scratch for any
+ * window of that map (make it outside a stream capture), later ones allocate
+ * nothing and can be captured. */
 int gtop_update_sdf_map_window(gtop_ctx *ctx, const double min_pos[3], const double max_pos[3],
                                const double *obstacle_pts, int npts);
 int gtop_update_sdf_map_window_device(gtop_ctx *ctx, const double min_pos[3], const double max_pos[3],

@@ -130,3 +130,55 @@ def test_gpu_window_update_is_bit_exact(gtop, oracle_mod):
                 torch.cuda.synchronize()
                 assert np.max(np.abs(c32.double().cpu().numpy() - c_ref) / np.abs(c_ref)) <= 2e-4
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_window_update_replays_from_a_hip_graph(gtop, oracle_mod):
+    """The per-frame loop of compare2.cpp:147-152 as ONE graph: window update (points read from a fixed HBM buffer) +
+    the evaluation behind it, captured once — after a first eager update of a SMALLER window has allocated the scratch,
+    which serves any window — and replayed with new points in the buffer: every replay leaves the field and the costs
+    of an eager context fed the same frames, bit for bit (fp64 and, the records of both precisions following, fp32)."""
+    import torch
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    grid, res = (40, 36, 20), 0.2
+    origin = np.array([-4.0, -3.6, 0.0])
+    map_size = (np.array(grid) - 0.5) * res
+    ms = type("M", (), {"origin": origin, "map_size": map_size})
+    bt = problem.make_trajectories(64, 4, ms, seed=9, margin=0.05, step_len=(0.3, 0.8))
+    first = (np.argwhere(rng.random(grid) < 0.02) + 0.5) * res + origin
+    a, b = origin + np.array([1.0, 1.2, 0.0]), origin + np.array([6.0, 5.5, 3.0])
+    frames = [rng.uniform(a - 0.2, b + 0.2, size=(50, 3)) for _ in range(3)]
+    ctxs = []
+    for _ in range(2):
+        c = gtop.GtopContext(device=0)
+        c.init_sdf_map(map_size, origin, res)
+        c.update_sdf_map(first)
+        c.set_params()
+        c.update_sdf_map_window(a + 1.0, a + 2.0, frames[0][:3])          # allocates the window scratch (uncaptured)
+        ctxs.append(c)
+    eager, graphed = ctxs
+    pts = torch.zeros(50, 3, dtype=torch.float64, device=dev)
+    ins = {td: [torch.tensor(v, dtype=td, device=dev) for v in (bt.x, bt.Df.reshape(-1, 18), bt.T)]
+           for td in (torch.float64, torch.float32)}
+    graphed.eval_device(*ins[torch.float32])                               # fp32 records in use: the window rebuilds both
+    eager.eval_device(*ins[torch.float32])
+    outs = {td: (torch.zeros(64, dtype=td, device=dev), torch.zeros(64, 27, dtype=td, device=dev)) for td in ins}
+    torch.cuda.synchronize()
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph):
+        graphed.update_sdf_map_window_device(a, b, pts)
+        for td in ins:
+            graphed.eval_device(*ins[td], *outs[td])
+    for f in frames:
+        pts.copy_(torch.tensor(f, device=dev))
+        gph.replay()
+        torch.cuda.synchronize()
+        eager.update_sdf_map_window(a, b, f)
+        assert np.array_equal(graphed.get_sdf(), eager.get_sdf())
+        for td in ins:
+            c_e, g_e = eager.eval_device(*ins[td])
+            torch.cuda.synchronize()
+            assert torch.equal(c_e, outs[td][0]) and torch.equal(g_e, outs[td][1])
+    for c in ctxs:
+        c.close()
