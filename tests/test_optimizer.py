@@ -487,3 +487,38 @@ def test_device_loop_lands_where_the_committed_traces_end(gtop, oracle_mod, name
     assert int(nev[0]) == int(g["nevals"]) and int(code[0]) == int(g["code"]), (nev, code, g["nevals"], g["code"])
     assert abs(costs[0] - float(g["minf"])) <= 1e-3 * abs(float(g["minf"]))
     assert np.max(np.abs(xs[0] - g["x"])) <= 1e-2 * max(1.0, np.max(np.abs(g["x"])))
+
+
+def test_launch_forms_agree_on_random_problems_at_both_geometries(scene, gtop):
+    """Random batch sizes (odd ones too: a last wavefront with a single trajectory), segment counts 2 .. 6, evaluation
+    caps and stop rules; one and two trajectories per wavefront: the three launch forms give the same bits, and a
+    trajectory's result does not depend on its place in the batch (whom it shares a wavefront with, first or second):
+    the same rows in reversed order give the reversed results."""
+    mp, ctx, sdf = scene
+    rng = np.random.default_rng(4242)
+    ctx.set_params()
+    try:
+        for draw in range(10):
+            B, m = int(rng.integers(1, 400)), int(rng.integers(2, 7))
+            cap = int(rng.integers(3, 45))
+            rule = [dict(), dict(ftol_rel=float(rng.choice([1e-2, 5e-2]))), dict(xtol_rel=float(rng.choice([0.05, 0.2])))][draw % 3]
+            b = problem.make_trajectories(B, m, mp, seed=6000 + draw)
+            lb, ub = gtop.GtopContext.default_bounds(b.waypoints)
+            for pin in (3, 6):
+                ctx.set_launch_geometry(0, pin)
+                ctx.set_problem(b.T, b.Df)
+                res = {}
+                for mode in (2, 1, 0):
+                    ctx.set_optimizer_fusion(mode)
+                    res[mode] = ctx.optimize_batch_ex(b.x, lb, ub, cap, **rule)
+                for mode in (1, 0):
+                    for a, r in zip(res[mode], res[2]):
+                        assert np.array_equal(a, r), (draw, B, m, pin, mode)
+                ctx.set_optimizer_fusion(2)
+                ctx.set_problem(b.T[::-1].copy(), b.Df[::-1].copy())
+                rev = ctx.optimize_batch_ex(b.x[::-1].copy(), lb[::-1].copy(), ub[::-1].copy(), cap, **rule)
+                for a, r in zip(rev, res[2]):
+                    assert np.array_equal(a[::-1], r), (draw, B, m, pin, "reversed")
+    finally:
+        ctx.set_optimizer_fusion(2)
+        ctx.set_launch_geometry(0, 0)
