@@ -48,6 +48,7 @@ struct gtop_rendezvous_slot {
   int index;
   bool active;       // still taking part
   bool waiting;      // has arrived for the current generation
+  bool in_call;      // its caller is inside gtop_cost_nlopt_shared (arrived, or awake again and copying its results out)
   int64_t calls;     // callbacks served (iter_num of this caller, grad_traj_optimizer.cpp:284)
   double best;       // running minimum of its costs (:439-447)
 };
@@ -66,7 +67,7 @@ struct gtop_rendezvous {
   std::atomic<uint32_t> generation{0};   // waiters sleep on this word (futex)
   int last_status = GTOP_OK;      // of the generation just evaluated
   std::atomic<bool> broken{false};   // gtop_rendezvous_abort, or a waiter's timeout: every call returns HUGE_VAL from then on
-  double timeout_s = 0.0;         // longest a caller waits for the others (0 = for ever)
+  std::atomic<double> timeout_s{0.0};   // longest a caller waits for the others (0 = for ever); may be set while callers wait
   double test_delay_s = 0.0;      // diagnostic (GTOP_RENDEZVOUS_TEST_DELAY_MS at create): the leader sleeps this long
                                   // before its launch, standing in for a slow first launch in the timeout tests
   int64_t launches = 0;
@@ -125,6 +126,21 @@ void break_rendezvous(gtop_rendezvous *r) {
   futex_wake_all(&r->generation);
 }
 
+struct CallGuard {   // the slot's caller is inside the callback until this goes out of scope; counts a served call
+  gtop_rendezvous *r;
+  gtop_rendezvous_slot *s;
+  bool served = false;
+  double cost = HUGE_VAL;
+  ~CallGuard() {
+    std::lock_guard<std::mutex> lk(r->mu);   // (gtop_rendezvous_stats / _leave look at these from other threads)
+    s->in_call = false;
+    if (served) {
+      s->calls++;
+      if (cost < s->best) s->best = cost;
+    }
+  }
+};
+
 struct InsideGuard {   // counts the threads inside an entry point (gtop_rendezvous_destroy waits for zero)
   gtop_rendezvous *r;
   explicit InsideGuard(gtop_rendezvous *r_) : r(r_) { r->inside.fetch_add(1, std::memory_order_acq_rel); }
@@ -168,7 +184,7 @@ int gtop_rendezvous_create(gtop_rendezvous **out, gtop_ctx *ctx, int n_slots, in
   r->spin = n_slots <= usable_cores() ? 20000u : 0u;
   if (const char *d = std::getenv("GTOP_RENDEZVOUS_TEST_DELAY_MS")) r->test_delay_s = std::atof(d) * 1e-3;
   r->slots.resize(n_slots);
-  for (int i = 0; i < n_slots; ++i) r->slots[i] = gtop_rendezvous_slot{r, i, true, false, 0, HUGE_VAL};
+  for (int i = 0; i < n_slots; ++i) r->slots[i] = gtop_rendezvous_slot{r, i, true, false, false, 0, HUGE_VAL};
   r->active = n_slots;
   r->x.assign((size_t)n_slots * r->n, 0.0);
   r->cost.assign(n_slots, 0.0);
@@ -212,15 +228,17 @@ double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *f
   {
     std::lock_guard<std::mutex> lk(r->mu);
     if (r->broken.load(std::memory_order_relaxed)) return HUGE_VAL;   // (broken between the test above and the lock)
-    if (!s->active || s->waiting) return HUGE_VAL;   // left already / re-entered from a second thread
+    if (!s->active || s->waiting || s->in_call) return HUGE_VAL;   // left already / re-entered from a second thread
     // (the row is this caller's own; the previous generation's launch has completed, or it could not be here)
     std::memcpy(&r->x[(size_t)s->index * n], x, n * sizeof(double));
     s->waiting = true;
+    s->in_call = true;
     r->arrived++;
     gen = r->generation.load(std::memory_order_relaxed);
     leader = r->arrived == r->active;
     if (leader) r->evaluating = true;
   }
+  CallGuard call{r, s};
   if (leader) {
     run_generation(r);   // the last arriver evaluates for everybody
   } else {
@@ -228,8 +246,9 @@ double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *f
     auto t0 = std::chrono::steady_clock::now();
     while (r->generation.load(std::memory_order_acquire) == gen) {
       double left = 0.0;
-      if (r->timeout_s > 0.0) {
-        left = r->timeout_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      const double timeout_s = r->timeout_s.load(std::memory_order_relaxed);
+      if (timeout_s > 0.0) {
+        left = timeout_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (left <= 0.0) {
           // The timeout is for a caller that never ARRIVES (it exited without gtop_rendezvous_leave).  Once everybody
           // has arrived the wait is for the leader's launch — a module load on the first call, a large batch — which
@@ -256,8 +275,8 @@ double gtop_cost_nlopt_shared(unsigned n, const double *x, double *grad, void *f
   if (r->last_status != GTOP_OK) return HUGE_VAL;
   const double c = r->cost[s->index];
   if (grad) std::memcpy(grad, &r->grad[(size_t)s->index * n], n * sizeof(double));
-  s->calls++;
-  if (c < s->best) s->best = c;
+  call.served = true;
+  call.cost = c;
   return c;
 } GTOP_CATCH_HUGE(nullptr)
 
@@ -271,7 +290,8 @@ int gtop_rendezvous_leave(gtop_rendezvous_slot *s) try {
     if (!s->active) return GTOP_OK;
     // the slot's own caller is blocked inside gtop_cost_nlopt_shared right now (a leave from another thread): taking
     // it out here would leave `arrived` counting a caller that is gone, and the others waiting for ever
-    if (s->waiting) return GTOP_ERR_STATE;
+    // — or awake again and still copying its results out of the buffers the next launch would overwrite
+    if (s->waiting || s->in_call) return GTOP_ERR_STATE;
     s->active = false;          // its row keeps its last x: evaluated along, never read
     r->active--;
     leader = r->active > 0 && r->arrived == r->active && !r->broken.load(std::memory_order_relaxed);   // the others were only waiting for this one
@@ -283,7 +303,7 @@ int gtop_rendezvous_leave(gtop_rendezvous_slot *s) try {
 
 int gtop_rendezvous_set_timeout(gtop_rendezvous *r, double seconds) try {
   if (!r || !(seconds >= 0.0)) return GTOP_ERR_INVALID;
-  r->timeout_s = seconds;
+  r->timeout_s.store(seconds, std::memory_order_relaxed);
   return GTOP_OK;
 } GTOP_CATCH_STATUS(nullptr)
 
