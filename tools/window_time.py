@@ -40,7 +40,12 @@ for g in [int(a) for a in sys.argv[1:]] or [200, 400]:
         sel = np.all((pts >= a) & (pts <= b), axis=1)
         dw = torch.tensor(pts[sel], device="cuda:0")
         us = timed(lambda: ctx.update_sdf_map_window_device(a, b, dw))
+        # the same update captured once (its scratch exists after the eager calls) and replayed: one graph launch per frame
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            ctx.update_sdf_map_window_device(a, b, dw)
+        us_g = timed(gph.replay)
         vox = np.prod(np.ceil(np.array(box) / mp.resolution))
         print(f"grid {g}^3: window {box} m = {int(vox)} voxels ({100 * vox / g ** 3:.2f} % of the map), {int(sel.sum())} points: "
-              f"{us:.1f} us = {full / us:.1f}x faster than the whole map", flush=True)
+              f"{us:.1f} us eager, {us_g:.1f} us as a replayed hipGraph = {full / us_g:.1f}x faster than the whole map", flush=True)
     ctx.close()
