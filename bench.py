@@ -265,11 +265,17 @@ def main():
 
     # Steps per graph.  Single GPU, no collective (the driver's N = 1 run): ALL steps of the timed region in one
     # hipGraph — no gaps between graphs inside the region (round 3: forty 50-kernel graphs put 3-5 % of launch gaps
-    # into a 2 000-step region).  With a collective: buckets of --bucket steps, one all-gather each, and at least two
-    # buckets whenever there are two steps, so that a gather always has kernels to hide behind.
+    # into a 2 000-step region).  With a collective: buckets of --bucket steps, one all-gather each.  Where the gathers
+    # are host-side asynchronous calls (gloo, or GTOP_BENCH_CAPTURE_GATHER=0) a gather runs beside the next bucket's
+    # kernels, so a short run is split in (at least) two buckets to have something to hide behind; where they are
+    # captured into the bucket graphs (RCCL, the default) they run in line behind their bucket's kernels — exposed by
+    # construction, see the measurements at the capture below — and a short run is ONE bucket: one gather, not two.
     MAX_GRAPH_STEPS = 4096
+    gathers_in_line = collective and backend == "nccl" and os.environ.get("GTOP_BENCH_CAPTURE_GATHER", "1") == "1"
     if not collective:
         G = max(1, min(args.steps, MAX_GRAPH_STEPS))
+    elif gathers_in_line:
+        G = max(1, min(args.bucket, args.steps))
     else:
         G = max(1, min(args.bucket, args.steps // 2 if args.steps >= 2 else 1))
     while args.steps % G:
@@ -329,8 +335,7 @@ def main():
         # with a collective (RCCL only): first try to capture the bucket's all-gather INTO its graph, behind the last
         # kernel — one graph launch per bucket and no collective call from the host (which costs ~50 us exposed per
         # short timed region); if RCCL cannot be captured here, fall back to graphs of kernels + host-side gathers
-        attempts = ([True] if (collective and backend == "nccl" and os.environ.get("GTOP_BENCH_CAPTURE_GATHER", "1") == "1")
-                    else []) + [False]
+        attempts = ([True] if gathers_in_line else []) + [False]
         for with_gather in attempts:
             try:
                 if with_gather:     # the communicator must exist (and have run once) before it is captured
@@ -353,6 +358,13 @@ def main():
                 torch.cuda.synchronize()
         if graphs is None:
             print("bench.py: using eager launches", file=sys.stderr)
+        # The captured all-gather of a bucket runs BEHIND the bucket's kernels, on the same stream: exposed by
+        # construction.  The two ways to run it beside the next bucket's kernels were built and measured at RCCL world
+        # size 1 (tools/calls/call_r4_20.sh, 20 steps in 2 buckets / 200 in 4, host us): one graph for the whole region
+        # with the gathers as forked branches 176 / 1 200; kernel graphs on the main stream and gather graphs on a side
+        # stream behind events 212 / 1 365; host-side async all-gather calls 195 / 1 213 — against 126 / 834 for this
+        # form (kernels alone: 122 / 841).  A cross-stream dependency costs this runtime tens of microseconds, more than
+        # a small all-gather can take; so the gathers stay in line, and a run has as few of them as its --bucket allows.
     if rank == 0:
         log(f"launch mode {launch_mode}, {G} steps per bucket x {nbuckets}, backend {backend if collective else 'none'}")
     run_bucket, drain = pipe.run_bucket, pipe.drain
@@ -550,6 +562,7 @@ def main():
                 # started directly or under torchrun; "collective": the bucketed path of N > 1
                 "path": "collective" if collective else "single",
                 "launch": launch_mode, "steps_per_bucket": G, "buckets": nbuckets, "graph_upload_replays": upload_replays,
+
                 "clock_warmup_ms": CLOCK_WARMUP_MS, "clock_warmup_steps": clock_warmup_buckets * G,
                 "gather": gather_mode,
                 "collective_bytes_per_bucket": (world * G * (hi - lo) * elem

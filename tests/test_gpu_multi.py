@@ -56,11 +56,16 @@ def test_bench_rank_path_with_host_side_gathers():
 
 
 @pytest.mark.timeout(900)
-def test_bench_short_collective_run_still_has_two_buckets():
-    """The driver's N > 1 command is --steps 20: with one bucket its single all-gather would sit fully exposed behind
-    the last kernel; the bench splits such a run in (at least) two buckets."""
-    r = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"],
-               {"GTOP_BENCH_FORCE_DIST": "1"})
+def test_bench_short_collective_run_and_its_buckets():
+    """The driver's N > 1 command is --steps 20.  With the all-gathers captured into the bucket graphs (RCCL) a gather
+    runs in line behind its bucket's kernels, so the run is ONE bucket — one exposed gather, not two (bench.py has the
+    measurements of the overlapping alternatives); with host-side asynchronous gathers, which do run beside the next
+    bucket's kernels, it is split in two."""
+    args = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"]
+    r = _bench(args, {"GTOP_BENCH_FORCE_DIST": "1"})
+    assert r["config"]["steps_per_bucket"] == 20 and r["config"]["buckets"] == 1 and r["steps"] == 20
+    assert r["config"]["gather"] == "captured in each bucket's hipGraph" and r["collective"]["collective_exposed_us"] is not None
+    r = _bench(args, {"GTOP_BENCH_FORCE_DIST": "1", "GTOP_BENCH_CAPTURE_GATHER": "0"})
     assert r["config"]["steps_per_bucket"] == 10 and r["config"]["buckets"] == 2 and r["steps"] == 20
 
 
