@@ -271,7 +271,11 @@ def main():
     # captured into the bucket graphs (RCCL, the default) they run in line behind their bucket's kernels — exposed by
     # construction, see the measurements at the capture below — and a short run is ONE bucket: one gather, not two.
     MAX_GRAPH_STEPS = 4096
-    gathers_in_line = collective and backend == "nccl" and os.environ.get("GTOP_BENCH_CAPTURE_GATHER", "1") == "1"
+    # GTOP_BENCH_GATHER: "push" (default) = the all-gather as point-to-point stores (gtop_push_rows: one kernel behind the
+    # bucket's last evaluation writes this rank's rows into every rank's buffer, the peers' buffers mapped over CUDA-IPC),
+    # falling back to "library" = the process group's all_gather_into_tensor (RCCL) when the buffers cannot be mapped
+    want_push = collective and os.environ.get("GTOP_BENCH_GATHER", "push") == "push"
+    gathers_in_line = collective and os.environ.get("GTOP_BENCH_CAPTURE_GATHER", "1") == "1" and (want_push or backend == "nccl")
     if not collective:
         G = max(1, min(args.steps, MAX_GRAPH_STEPS))
     elif gathers_in_line:
@@ -318,6 +322,11 @@ def main():
                                 n_free=n, gather_grads=args.gather_grads, collective=collective)
     launch_mode = "eager"
     gather_mode = "none" if not collective else "host call per bucket, overlapped with the next bucket"
+    push_mode, push_note = False, None
+    if want_push:
+        push_mode, push_note = pipe.enable_push(ctx)
+        if rank == 0:
+            log(f"gather by point-to-point stores: {'on' if push_mode else 'OFF, library all-gather instead — ' + push_note}")
     nrings = 2 if collective else min(2, nbuckets)
     kernel_graphs = None                 # the same buckets without their all-gather (collective runs: what the gather costs)
     if not args.no_graph:
@@ -335,7 +344,7 @@ def main():
         # with a collective (RCCL only): first try to capture the bucket's all-gather INTO its graph, behind the last
         # kernel — one graph launch per bucket and no collective call from the host (which costs ~50 us exposed per
         # short timed region); if RCCL cannot be captured here, fall back to graphs of kernels + host-side gathers
-        attempts = ([True] if gathers_in_line else []) + [False]
+        attempts = ([True] if (gathers_in_line and (push_mode or backend == "nccl")) else []) + [False]
         for with_gather in attempts:
             try:
                 if with_gather:     # the communicator must exist (and have run once) before it is captured
@@ -347,7 +356,8 @@ def main():
                 pipe.gather_in_bucket_fn = with_gather
                 launch_mode = "hipgraph"
                 if with_gather:
-                    gather_mode = "captured in each bucket's hipGraph"
+                    gather_mode = ("point-to-point stores (gtop_push_rows), captured in each bucket's hipGraph" if push_mode
+                                   else "captured in each bucket's hipGraph")
                     kernel_graphs = capture(False)
                 else:
                     kernel_graphs = graphs
@@ -418,6 +428,17 @@ def main():
         drain()
         torch.cuda.synchronize()
 
+    # ---- the collectives the timed region's bracket itself uses (the start-time broadcast, the barrier), once, untimed:
+    #      RCCL sets an operation's channels up lazily at its first use, and part of that work ran INTO a short region
+    #      (the first 20-step region of a process read 170-280 us, every later one 114: tools/calls/call_r4_26.sh)
+    if collective and os.environ.get("GTOP_BENCH_WARM_BRACKET", "1") == "1":
+        for _ in range(2):
+            tw = torch.tensor([0.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.broadcast(tw, 0)
+            tw.item()
+            dist.barrier()
+        torch.cuda.synchronize()
+
     # ---- timed region: exactly K = nbuckets*G steps ----
     def timed_region(run_b):
         """K steps through run_b(bucket), bracketed by barrier + synchronize on both sides.  Returns this rank's host
@@ -450,7 +471,20 @@ def main():
         st = stamps.tolist()
         return t1 - t0, (st[1] - st[0]) / clock_hz
 
+    # Collective runs: one untimed rehearsal of the whole bracket first (declared in `config`).  The first region of a
+    # process is not like the others — with RCCL's captured all-gather in the buckets it read 170-290 us where every later
+    # one reads 114 (world size 1, tools/calls/call_r4_26.sh), its 20 kernels themselves spread over 140-250 us — a
+    # one-time cost of the communication library's first synchronised use, like the graphs' upload, not a step's.
+    region_rehearsals = 0
+    if collective and os.environ.get("GTOP_BENCH_REHEARSE_REGION", "1") == "1":
+        timed_region(run_bucket)
+        region_rehearsals = 1
     elapsed, gpu_elapsed = timed_region(run_bucket)
+    if os.environ.get("GTOP_BENCH_REGION_REPEATS"):      # diagnostic: the same region again, to see its run-to-run spread
+        for k in range(int(os.environ["GTOP_BENCH_REGION_REPEATS"])):
+            e2, g2 = timed_region(run_bucket)
+            if rank == 0:
+                log(f"region repeat {k}: host {e2 * 1e6:.1f} us, device span {g2 * 1e6:.1f} us (first: {elapsed * 1e6:.1f} / {gpu_elapsed * 1e6:.1f})")
     kern_ms_host = elapsed * 1e3 / args.steps
     kern_ms_gpu = gpu_elapsed * 1e3 / args.steps
     timed_src = (f"device wall clock ({clock_hz / 1e6:.0f} MHz) stamped by a one-lane kernel in front of the first and behind "
@@ -518,6 +552,11 @@ def main():
         assert torch.equal(last[rank], pipe.cost_ring[(nbuckets - 1) & 1])
         if args.gather_grads:
             assert torch.equal(pipe.all_grads(nbuckets - 1)[rank], pipe.grad_ring[(nbuckets - 1) & 1])
+        if push_mode:
+            # the rows the peers stored here against the process group's own all-gather of the same ring
+            jl = (nbuckets - 1) & 1
+            assert torch.equal(pipe.gathered[jl], pipe.library_all_gather_of_ring(jl)), \
+                "rows pushed by the peers differ from the library all-gather"
         if rank == 0 and parity is not None:
             # rank r's rows of the gathered costs are that rank's shard: check rank 0's against the parity launch
             c_chk, _ = ctx.eval_device(x, Df, T)
@@ -564,6 +603,7 @@ def main():
                 "launch": launch_mode, "steps_per_bucket": G, "buckets": nbuckets, "graph_upload_replays": upload_replays,
 
                 "clock_warmup_ms": CLOCK_WARMUP_MS, "clock_warmup_steps": clock_warmup_buckets * G,
+                "untimed_region_rehearsals": region_rehearsals,
                 "gather": gather_mode,
                 "collective_bytes_per_bucket": (world * G * (hi - lo) * elem
                                                 + (world * (hi - lo) * n * elem if args.gather_grads else 0))
@@ -606,6 +646,9 @@ def main():
             ko = max(by_rank["kernels_only_host_s"]) if kernels_only else None
             out["collective"] = {
                 "backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                # how the costs travel: "push" = gtop_push_rows (stores into the peers' mapped buffers, checked above
+                # against the library all-gather), "library" = the process group's all_gather_into_tensor
+                "gather_impl": "push" if push_mode else "library", "push_note": push_note,
                 "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
                 "elapsed_s_by_rank": by_rank["host_s"], "elapsed_s_min": min(by_rank["host_s"]),
                 "elapsed_s_max": max(by_rank["host_s"]),
@@ -632,6 +675,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     if collective:
+        pipe.close_push()
         dist.destroy_process_group()
 
 

@@ -126,6 +126,11 @@ def load_library():
         "gtop_update_sdf_map_window_device": (C.c_int, [vp, dp, dp, vp, C.c_int, vp]),
         "gtop_set_field_precisions": (C.c_int, [vp, C.c_int]),
         "gtop_device_clock_stamp": (C.c_int, [vp, vp, vp]),
+        "gtop_push_rows": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, vp]),
+        "gtop_shared_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p]),
+        "gtop_shared_open": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_void_p)]),
+        "gtop_shared_close": (C.c_int, [vp, vp]),
+        "gtop_shared_free": (C.c_int, [vp, vp]),
         "gtop_device_clock_hz": (C.c_int, [vp, dp]),
         "gtop_rendezvous_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
         "gtop_rendezvous_destroy": (C.c_int, [vp]),
@@ -350,6 +355,38 @@ class GtopContext:
     def set_field_precisions(self, keep_fp32=True):
         """False: keep fp64 corner records only (the capturable map updates then skip the fp32 pass; fp32 evaluations fail)."""
         self._chk(self._L.gtop_set_field_precisions(self._h, 1 if keep_fp32 else 0))
+
+    def push_rows(self, src, dst_ptrs, nbytes=None, stream=None):
+        """ONE kernel copies `src` (a contiguous CUDA tensor, or its first nbytes) to every device address in dst_ptrs
+        (ints: slots in this process's and in peers' mapped buffers) — gtop_push_rows, the all-gather as stores."""
+        import torch
+        assert src.is_cuda and src.is_contiguous()
+        if nbytes is None:
+            nbytes = src.numel() * src.element_size()
+        if stream is None:
+            stream = torch.cuda.current_stream(src.device).cuda_stream
+        arr = (C.c_void_p * len(dst_ptrs))(*[int(p) for p in dst_ptrs])
+        self._chk(self._L.gtop_push_rows(self._h, C.c_void_p(src.data_ptr()), int(nbytes), arr, len(dst_ptrs),
+                                         C.c_void_p(stream)))
+
+    def shared_alloc(self, nbytes):
+        """(device address, 64-byte handle) of a zeroed allocation another process can map (gtop_shared_alloc)."""
+        ptr = C.c_void_p()
+        h = C.create_string_buffer(64)
+        self._chk(self._L.gtop_shared_alloc(self._h, int(nbytes), C.byref(ptr), h))
+        return int(ptr.value), bytes(h.raw)
+
+    def shared_open(self, handle):
+        """Device address, for this context's device, of a buffer a peer process made with shared_alloc."""
+        ptr = C.c_void_p()
+        self._chk(self._L.gtop_shared_open(self._h, C.create_string_buffer(bytes(handle), 64), C.byref(ptr)))
+        return int(ptr.value)
+
+    def shared_close(self, ptr):
+        self._chk(self._L.gtop_shared_close(self._h, C.c_void_p(int(ptr))))
+
+    def shared_free(self, ptr):
+        self._chk(self._L.gtop_shared_free(self._h, C.c_void_p(int(ptr))))
 
     def clock_stamp(self, minmax, stream=None):
         """Enqueue a device-clock stamp: minmax (torch int64 tensor of 2 on the device, preset to [2**63 - 1, 0])

@@ -1162,6 +1162,78 @@ int gtop_device_clock_stamp(gtop_ctx *c, void *d_minmax, void *hip_stream) try {
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)
 
+// ---- SURVEY 8e's collective as point-to-point stores (gtop_push.hip) ----
+int gtop_push_rows(gtop_ctx *c, const void *d_src, size_t bytes, void *const *d_dsts, int n_dsts, void *hip_stream) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (n_dsts < 0 || n_dsts > GTOP_PUSH_MAX_DSTS || (bytes > 0 && n_dsts > 0 && (!d_src || !d_dsts)))
+    return fail(c, GTOP_ERR_INVALID, "push_rows: 0 .. 16 destinations, non-NULL buffers");
+  if (bytes == 0 || n_dsts == 0) return GTOP_OK;
+  GtopPushDsts dsts{};
+  if (reinterpret_cast<uintptr_t>(d_src) & 15u) return fail(c, GTOP_ERR_INVALID, "push_rows: source not 16-byte aligned");
+  for (int k = 0; k < n_dsts; ++k) {
+    if (!d_dsts[k] || (reinterpret_cast<uintptr_t>(d_dsts[k]) & 15u))
+      return fail(c, GTOP_ERR_INVALID, "push_rows: a destination is NULL or not 16-byte aligned");
+    dsts.p[k] = d_dsts[k];
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, gtop_launch_push_rows(d_src, bytes, dsts, n_dsts, static_cast<hipStream_t>(hip_stream)));
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
+// Buffers another process can map: plain hipMalloc allocations (an IPC handle names a whole allocation: a
+// sub-allocation of a caching allocator would not do) exported / opened with HIP's IPC calls.  A peer's buffer is
+// opened with THIS context's device current and lazy peer access: the mapping is made for the device whose kernels
+// will store into it (what RCCL's own point-to-point transport does).
+int gtop_shared_alloc(gtop_ctx *c, size_t bytes, void **d_ptr, unsigned char handle[GTOP_IPC_HANDLE_BYTES]) try {
+  if (!c) return GTOP_ERR_INVALID;
+  static_assert(sizeof(hipIpcMemHandle_t) <= GTOP_IPC_HANDLE_BYTES, "handle size");
+  if (!d_ptr || !handle || bytes == 0) return fail(c, GTOP_ERR_INVALID, "shared_alloc: bytes > 0, non-NULL outputs");
+  *d_ptr = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  void *p = nullptr;
+  HIPCHK(c, hipMalloc(&p, bytes));
+  hipError_t e = hipMemset(p, 0, bytes);
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    HIPCHK(c, e);
+  }
+  std::memset(handle, 0, GTOP_IPC_HANDLE_BYTES);
+  std::memcpy(handle, &h, sizeof(h));
+  *d_ptr = p;
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
+int gtop_shared_open(gtop_ctx *c, const unsigned char handle[GTOP_IPC_HANDLE_BYTES], void **d_ptr) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!d_ptr || !handle) return fail(c, GTOP_ERR_INVALID, "shared_open: NULL argument");
+  *d_ptr = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle, sizeof(h));
+  void *p = nullptr;
+  HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  *d_ptr = p;
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
+int gtop_shared_close(gtop_ctx *c, void *d_ptr) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!d_ptr) return GTOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipIpcCloseMemHandle(d_ptr));
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
+int gtop_shared_free(gtop_ctx *c, void *d_ptr) try {
+  if (!c) return GTOP_ERR_INVALID;
+  if (!d_ptr) return GTOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipFree(d_ptr));
+  return GTOP_OK;
+} GTOP_CATCH_STATUS(c)
+
 int gtop_device_clock_hz(gtop_ctx *c, double *hz) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!hz) return fail(c, GTOP_ERR_INVALID, "device_clock_hz: NULL");

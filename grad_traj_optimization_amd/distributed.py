@@ -14,6 +14,12 @@ as well — what a global optimizer step that runs once per bucket would consume
 point, so that gather is per-link bound; it rides behind the next bucket's
 kernels like the cost gather does.
 
+`enable_push(ctx)` replaces the library all-gather by point-to-point stores (csrc/gtop_push.hip, gtop_push_rows): every
+rank maps every peer's gathered buffers into its own process (CUDA-IPC handles exchanged once through the process
+group) and ONE kernel behind a bucket's last evaluation stores the rank's rows into its slot of every buffer — no
+collective launch, no ring protocol; the owners read after the closing barrier.  Verified against the process group's own
+all-gather before it is trusted; any failure leaves the library path in place.
+
 `ResultGatherPipeline` is backend-agnostic (nccl on GPUs; gloo on CPU for the
 tests, and gloo with device buffers staged through the host for rehearsals on a
 one-GPU box); the evaluation itself is injected as `run_bucket_fn(ring_index)`,
@@ -26,6 +32,13 @@ import torch.distributed as dist
 from .problem import shard_range  # re-exported: the batch partition rule
 
 __all__ = ["shard_range", "ResultGatherPipeline", "CostGatherPipeline"]
+
+
+class _DeviceBytes:
+    """A raw device allocation as something torch.as_tensor can wrap without copying (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
 
 
 class ResultGatherPipeline:
@@ -57,6 +70,116 @@ class ResultGatherPipeline:
         # True when run_bucket_fn enqueues the all-gathers itself (captured into the bucket's hipGraph behind its last
         # kernel: one graph launch per bucket, no collective call from the host)
         self.gather_in_bucket_fn = False
+        self._push = None                   # enable_push: (ctx, per ring: destination addresses of the cost rows / of the gradient)
+        self._shared = None                 # (ctx, the peers' mapped buffers, this rank's own shareable allocations)
+
+    def enable_push(self, ctx):
+        """Switch the gathers to gtop_push_rows.  Every rank must call this together, before the first bucket.
+        The gathered buffers move into allocations of their own that a peer process can map (gtop_shared_alloc: an IPC
+        handle names a whole allocation, not a slice of torch's caching allocator); the 64-byte handles travel through
+        the process group; every rank maps every peer's buffers FOR ITS OWN DEVICE (gtop_shared_open: lazy peer access
+        — what RCCL's own point-to-point transport does).  Returns (ok, why): ok only if EVERY rank mapped every
+        peer's buffers and a probe push arrived intact everywhere — decided together, so that all ranks take the same
+        path; otherwise nothing has changed and the library all-gather stays in place."""
+        if not self.collective:
+            return False, "no collective"
+        why = "ok"
+        dsts = None
+        opened, owned = [], []
+        try:
+            old = [self.gathered[0], self.gathered[1]] + (list(self.grad_gathered) if self.gather_grads else [])
+            dev = old[0].device
+            mine, views = [], []
+            for t in old:
+                nbytes = t.numel() * t.element_size()
+                ptr, handle = ctx.shared_alloc(nbytes)
+                owned.append(ptr)
+                mine.append(handle)
+                views.append(torch.as_tensor(_DeviceBytes(ptr, nbytes), device=dev).view(t.dtype).view(t.shape))
+            allh = [None] * self.world
+            dist.all_gather_object(allh, mine)
+            base = []                           # [rank][buffer] -> device address of that rank's buffer in THIS process
+            for r in range(self.world):
+                if r == self.rank:
+                    base.append(list(owned))
+                    continue
+                row = []
+                for h in allh[r]:
+                    p = ctx.shared_open(h)
+                    opened.append(p)
+                    row.append(p)
+                base.append(row)
+            es = old[0].element_size()
+            cost_bytes = self.G * self.cost_ring[0].shape[1] * es
+            dsts = {"cost": [[base[r][j] + self.rank * cost_bytes for r in range(self.world)] for j in range(2)],
+                    "cost_bytes": cost_bytes}
+            if self.gather_grads:
+                gb = self.grad_ring[0].numel() * es
+                dsts["grad"] = [[base[r][2 + j] + self.rank * gb for r in range(self.world)] for j in range(2)]
+                dsts["grad_bytes"] = gb
+        except Exception as e:                  # (a handle that cannot be opened, no peer access, ...)
+            why = f"mapping the peers' buffers failed: {e!r}"
+            dsts = None
+        # probe: every rank pushes a rank-coded pattern through the real path; every rank checks every slot
+        ok_local = dsts is not None
+        saved = (self.gathered, self.grad_gathered)
+        if ok_local:
+            try:
+                self.gathered = [views[0], views[1]]
+                if self.gather_grads:
+                    self.grad_gathered = [views[2], views[3]]
+                self._push = (ctx, dsts)
+                for j in range(2):
+                    self.cost_ring[j].fill_(float(self.rank + 1) + 0.25 * j)
+                    self.gathered[j].fill_(-7.0)
+                torch.cuda.synchronize()
+            except Exception as e:
+                ok_local, why = False, f"probe set-up failed: {e!r}"
+        dist.barrier()                          # nobody pushes into a buffer its owner is still presetting
+        if ok_local:
+            try:
+                for j in range(2):
+                    ctx.push_rows(self.cost_ring[j], dsts["cost"][j], dsts["cost_bytes"])
+                torch.cuda.synchronize()
+            except Exception as e:
+                ok_local, why = False, f"probe push failed: {e!r}"
+        dist.barrier()
+        if ok_local:
+            for j in range(2):
+                g = self.gathered[j].view(self.world, -1)
+                want = torch.arange(1, self.world + 1, dtype=g.dtype, device=g.device) + 0.25 * j
+                if not bool((g == want[:, None]).all()):
+                    ok_local, why = False, f"probe rows of ring {j} did not all arrive"
+        flags = [None] * self.world
+        dist.all_gather_object(flags, (bool(ok_local), why))
+        ok = all(f[0] for f in flags)
+        for j in range(2):
+            self.cost_ring[j].zero_()
+        torch.cuda.synchronize()
+        if ok:
+            for j in range(2):
+                self.gathered[j].zero_()
+            torch.cuda.synchronize()
+            self._shared = (ctx, opened, owned)
+        else:
+            self._push = None
+            self.gathered, self.grad_gathered = saved
+            why = "; ".join(f"rank {r}: {f[1]}" for r, f in enumerate(flags) if not f[0])
+            views = None
+            dist.barrier()                      # every rank has stopped using the mappings
+            for p in opened:
+                try:
+                    ctx.shared_close(p)
+                except Exception:
+                    pass
+            dist.barrier()                      # ... and closed them, before their owners free them
+            for p in owned:
+                try:
+                    ctx.shared_free(p)
+                except Exception:
+                    pass
+        dist.barrier()
+        return ok, why
 
     def _gather(self, out, src):
         if self._staged:
@@ -76,16 +199,54 @@ class ResultGatherPipeline:
         j = b & 1
         self._wait(j)                       # ring j is about to be overwritten
         self.run_bucket_fn(j)
-        if self.collective and not self.gather_in_bucket_fn:
+        if self.collective and not self.gather_in_bucket_fn and self._push is not None:
+            self.gather_now(j)              # stores enqueued behind the bucket's kernels: nothing to wait for on the host
+        elif self.collective and not self.gather_in_bucket_fn:
             self._pending[j].append(self._gather(self.gathered[j], self.cost_ring[j]))
             if self.gather_grads:
                 self._pending[j].append(self._gather(self.grad_gathered[j], self.grad_ring[j]))
 
     def gather_now(self, j):
         """The bucket's all-gathers, synchronously on the current stream (for capture into the bucket's graph)."""
+        if self._push is not None:
+            ctx, d = self._push
+            ctx.push_rows(self.cost_ring[j], d["cost"][j], d["cost_bytes"])
+            if self.gather_grads:
+                ctx.push_rows(self.grad_ring[j], d["grad"][j], d["grad_bytes"])
+            return
         dist.all_gather_into_tensor(self.gathered[j], self.cost_ring[j])
         if self.gather_grads:
             dist.all_gather_into_tensor(self.grad_gathered[j], self.grad_ring[j])
+
+    def close_push(self):
+        """Unmap the peers' buffers and release this rank's own (the owners must outlive the mappings: barriers)."""
+        if self._shared is None:
+            return
+        ctx, opened, owned = self._shared
+        torch.cuda.synchronize()
+        dist.barrier()
+        self._push = None
+        self._shared = None
+        self.gathered = [g.clone() for g in self.gathered]          # (results stay readable: ordinary tensors again)
+        if self.gather_grads:
+            self.grad_gathered = [g.clone() for g in self.grad_gathered]
+        torch.cuda.synchronize()
+        for p in opened:
+            ctx.shared_close(p)
+        dist.barrier()
+        for p in owned:
+            ctx.shared_free(p)
+
+    def library_all_gather_of_ring(self, j):
+        """Ring j's costs of every rank through the process group's own all-gather (a check for the push path)."""
+        out = torch.zeros_like(self.gathered[j])
+        if self._staged:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, self.cost_ring[j].cpu())
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, self.cost_ring[j])
+        return out
 
     def drain(self):
         for j in range(2):

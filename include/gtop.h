@@ -486,6 +486,34 @@ int gtop_set_optimizer_fusion(gtop_ctx *ctx, int fused);
  * (fusion 1 or 2). */
 int gtop_set_optimizer_precision(gtop_ctx *ctx, int dtype);
 
+/* ---- collecting the shards' results (not in the reference) -- */
+
+/* The all-gather of a rank's result rows as point-to-point stores: ONE kernel on
+ * `hip_stream` copies `bytes` from d_src to each of the n_dsts (<= 16) device
+ * pointers of d_dsts — this rank's slot in its own gathered buffer and in every
+ * peer's, the peers' buffers mapped into this process (hipIpcOpenMemHandle
+ * between the one-process-per-GPU ranks, peer access inside one process), each
+ * destination over its own xGMI link.  Every rank's slot is written by that rank
+ * alone, so no protocol is needed; an owner may read its buffer after any
+ * synchronisation that orders the read behind the writers' kernels (the closing
+ * barrier of a timed region).  All pointers 16-byte aligned.  Asynchronous,
+ * capturable.  bench.py's N > 1 runs gather their costs this way, with RCCL's
+ * all-gather as the fallback when the peers' buffers cannot be mapped. */
+int gtop_push_rows(gtop_ctx *ctx, const void *d_src, size_t bytes, void *const *d_dsts, int n_dsts,
+                   void *hip_stream);
+/* Buffers for it that another process can map.  gtop_shared_alloc: a zeroed
+ * device allocation of its own (an IPC handle names a whole allocation) on the
+ * context's device and its 64-byte handle, to be sent to the peers by any means;
+ * gtop_shared_open maps a PEER's buffer (a handle made in another process) for
+ * the context's device — the device whose kernels will store into it — with lazy
+ * peer access; gtop_shared_close unmaps it; gtop_shared_free releases an
+ * allocation of gtop_shared_alloc (after the peers have closed it). */
+#define GTOP_IPC_HANDLE_BYTES 64
+int gtop_shared_alloc(gtop_ctx *ctx, size_t bytes, void **d_ptr, unsigned char handle[GTOP_IPC_HANDLE_BYTES]);
+int gtop_shared_open(gtop_ctx *ctx, const unsigned char handle[GTOP_IPC_HANDLE_BYTES], void **d_ptr);
+int gtop_shared_close(gtop_ctx *ctx, void *d_ptr);
+int gtop_shared_free(gtop_ctx *ctx, void *d_ptr);
+
 /* ---- measurement aid (not in the reference) --------------------------- */
 
 /* Enqueues a one-lane kernel on `hip_stream` that reads the device's constant-

@@ -745,3 +745,26 @@ def test_field_precisions_knob(scene, oracle_mod, gtop):
     rc, rg = scenes.rel_err(c32.double().cpu().numpy(), g32.double().cpu().numpy(), c_ref, g_ref)
     assert rc <= TOL32 and rg <= TOL32
     ctx.close()
+
+
+def test_push_rows_copies_to_every_destination(gtop):
+    """gtop_push_rows inside one process: odd byte counts, offsets into larger buffers, 1 .. 16 destinations, the
+    source among them; misaligned or too many destinations refused."""
+    import torch
+    ctx = gtop.GtopContext(device=0)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    for nbytes, ndst in ((16, 1), (4096 + 8, 3), (1 << 20, 8), (163840, 16), (7, 2)):
+        src = torch.tensor(rng.integers(0, 255, size=nbytes + 64, dtype=np.uint8), device=dev)
+        bufs = [torch.full((nbytes + 256,), 255, dtype=torch.uint8, device=dev) for _ in range(ndst)]
+        ctx.push_rows(src, [b.data_ptr() + 128 for b in bufs], nbytes)
+        torch.cuda.synchronize()
+        for b in bufs:
+            assert torch.equal(b[128:128 + nbytes], src[:nbytes])
+            assert bool((b[:128] == 255).all()) and bool((b[128 + nbytes:] == 255).all())     # nothing beyond the rows
+    src = torch.zeros(64, dtype=torch.uint8, device=dev)
+    with pytest.raises(gtop.GtopError):
+        ctx.push_rows(src, [src.data_ptr() + 8], 16)                  # misaligned destination
+    with pytest.raises(gtop.GtopError):
+        ctx.push_rows(src, [src.data_ptr()] * 17, 16)                 # more than 16 destinations
+    ctx.close()

@@ -37,7 +37,9 @@ def test_bench_rank_path_with_rccl_at_world_size_one():
     assert r["config"]["launch"] == "hipgraph" and r["config"]["steps_per_bucket"] == 10
     assert r["config"]["collective_bytes_per_bucket"] == 10 * 1024 * 8 + 1024 * 45 * 8
     assert r["parity"]["ok"] and r["value"] > 1e4
-    assert r["config"]["gather"] == "captured in each bucket's hipGraph"
+    assert r["config"]["gather"] == "point-to-point stores (gtop_push_rows), captured in each bucket's hipGraph"
+    assert r["collective"]["gather_impl"] == "push"
+    assert r["config"]["untimed_region_rehearsals"] == 1          # (collective runs only; declared)
     assert r["config"]["path"] == "collective" and r["config"]["buckets"] == 4
     col = r["collective"]
     assert col["backend"] == "nccl" and col["ranks"] == col["rccl_ranks"] == 1
@@ -50,7 +52,8 @@ def test_bench_rank_path_with_rccl_at_world_size_one():
 def test_bench_rank_path_with_host_side_gathers():
     # the fallback when RCCL cannot be captured: graphs of kernels, one async all-gather call per bucket
     r = _bench(["--gpus", "1", "--steps", "40", "--warmup", "7", "--bucket", "10", "--gather-grads",
-                "--no-extras", "--no-cpu-baseline"], {"GTOP_BENCH_FORCE_DIST": "1", "GTOP_BENCH_CAPTURE_GATHER": "0"})
+                "--no-extras", "--no-cpu-baseline"],
+               {"GTOP_BENCH_FORCE_DIST": "1", "GTOP_BENCH_CAPTURE_GATHER": "0", "GTOP_BENCH_GATHER": "library"})
     assert r["config"]["launch"] == "hipgraph" and r["config"]["gather"].startswith("host call per bucket")
     assert r["parity"]["ok"] and r["value"] > 1e4
 
@@ -62,10 +65,13 @@ def test_bench_short_collective_run_and_its_buckets():
     measurements of the overlapping alternatives); with host-side asynchronous gathers, which do run beside the next
     bucket's kernels, it is split in two."""
     args = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"]
-    r = _bench(args, {"GTOP_BENCH_FORCE_DIST": "1"})
+    r = _bench(args, {"GTOP_BENCH_FORCE_DIST": "1", "GTOP_BENCH_GATHER": "library"})      # RCCL's all-gather, captured
     assert r["config"]["steps_per_bucket"] == 20 and r["config"]["buckets"] == 1 and r["steps"] == 20
     assert r["config"]["gather"] == "captured in each bucket's hipGraph" and r["collective"]["collective_exposed_us"] is not None
-    r = _bench(args, {"GTOP_BENCH_FORCE_DIST": "1", "GTOP_BENCH_CAPTURE_GATHER": "0"})
+    assert r["collective"]["gather_impl"] == "library"
+    r = _bench(args, {"GTOP_BENCH_FORCE_DIST": "1"})                                      # the default: stores
+    assert r["config"]["buckets"] == 1 and r["collective"]["gather_impl"] == "push"
+    r = _bench(args, {"GTOP_BENCH_FORCE_DIST": "1", "GTOP_BENCH_CAPTURE_GATHER": "0", "GTOP_BENCH_GATHER": "library"})
     assert r["config"]["steps_per_bucket"] == 10 and r["config"]["buckets"] == 2 and r["steps"] == 20
 
 
@@ -88,6 +94,7 @@ def test_gpus_1_is_the_single_path_however_it_is_started():
         assert r["config"]["steps_per_bucket"] == 20 and r["config"]["buckets"] == 1 and r["config"]["gather"] == "none"
         assert r["roofline"]["frac_source"] == "timed_region_gpu"
         assert r["config"]["clock_warmup_ms"] == 40.0 and r["config"]["clock_warmup_steps"] >= 20
+        assert r["config"]["untimed_region_rehearsals"] == 0
         f = r["roofline"]["frac_by_source"]
         assert abs(f["timed_region_gpu"] - f["probe"]) <= 0.08 * f["probe"], f      # two clocks, one kernel
         assert abs(r["roofline"]["frac"] - f["timed_region_gpu"]) < 1e-12
@@ -105,7 +112,11 @@ def test_bench_self_launches_two_ranks_on_one_card():
     col = r["collective"]
     assert col["backend"] == "gloo" and col["ranks"] == 2 and col["rccl_ranks"] == 0
     assert len(col["elapsed_s_by_rank"]) == 2 and col["elapsed_s_max"] >= col["elapsed_s_min"] > 0
-    assert r["config"]["buckets"] == 2 and r["config"]["path"] == "collective"
+    # TWO PROCESSES storing into each other's buffers (mapped over CUDA-IPC; here both on one card): the push path the
+    # ranks of a real node take, checked inside bench.py against the process group's own all-gather
+    assert col["gather_impl"] == "push", col["push_note"]
+    assert r["config"]["gather"].startswith("point-to-point stores") and r["config"]["launch"] == "hipgraph"
+    assert r["config"]["buckets"] == 1 and r["config"]["path"] == "collective"
 
 
 def test_two_contexts_on_one_device_equal_the_unsharded_batch(gtop):
