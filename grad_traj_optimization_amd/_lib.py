@@ -128,7 +128,7 @@ def load_library():
         "gtop_device_clock_stamp": (C.c_int, [vp, vp, vp]),
         "gtop_push_rows": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, vp]),
         "gtop_shared_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p]),
-        "gtop_shared_open": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_void_p)]),
+        "gtop_shared_open": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
         "gtop_shared_close": (C.c_int, [vp, vp]),
         "gtop_shared_free": (C.c_int, [vp, vp]),
         "gtop_device_clock_hz": (C.c_int, [vp, dp]),
@@ -376,10 +376,12 @@ class GtopContext:
         self._chk(self._L.gtop_shared_alloc(self._h, int(nbytes), C.byref(ptr), h))
         return int(ptr.value), bytes(h.raw)
 
-    def shared_open(self, handle):
-        """Device address, for this context's device, of a buffer a peer process made with shared_alloc."""
+    def shared_open(self, handle, owner_device=-1):
+        """Device address, for this context's device, of a buffer a peer process made with shared_alloc (owner_device:
+        that process's device ordinal, so that peer access is checked and enabled first)."""
         ptr = C.c_void_p()
-        self._chk(self._L.gtop_shared_open(self._h, C.create_string_buffer(bytes(handle), 64), C.byref(ptr)))
+        self._chk(self._L.gtop_shared_open(self._h, C.create_string_buffer(bytes(handle), 64), int(owner_device),
+                                           C.byref(ptr)))
         return int(ptr.value)
 
     def shared_close(self, ptr):

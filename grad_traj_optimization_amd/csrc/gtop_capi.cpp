@@ -1205,11 +1205,24 @@ int gtop_shared_alloc(gtop_ctx *c, size_t bytes, void **d_ptr, unsigned char han
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)
 
-int gtop_shared_open(gtop_ctx *c, const unsigned char handle[GTOP_IPC_HANDLE_BYTES], void **d_ptr) try {
+int gtop_shared_open(gtop_ctx *c, const unsigned char handle[GTOP_IPC_HANDLE_BYTES], int owner_device, void **d_ptr) try {
   if (!c) return GTOP_ERR_INVALID;
   if (!d_ptr || !handle) return fail(c, GTOP_ERR_INVALID, "shared_open: NULL argument");
   *d_ptr = nullptr;
   HIPCHK(c, hipSetDevice(c->device));
+  // The owner's device, when the caller knows it: no mapping is made unless this device can reach that one (a kernel
+  // storing through a mapping its GPU cannot reach faults the whole process), and peer access is switched on here
+  // rather than left to the lazy flag alone.
+  if (owner_device >= 0 && owner_device != c->device) {
+    int ndev = 0, can = 0;
+    HIPCHK(c, hipGetDeviceCount(&ndev));
+    if (owner_device >= ndev) return fail(c, GTOP_ERR_INVALID, "shared_open: the owner's device ordinal is not visible to this process");
+    HIPCHK(c, hipDeviceCanAccessPeer(&can, c->device, owner_device));
+    if (!can) return fail(c, GTOP_ERR_STATE, "shared_open: this device has no peer access to the owner's device");
+    const hipError_t pe = hipDeviceEnablePeerAccess(owner_device, 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) HIPCHK(c, pe);
+    (void)hipGetLastError();   // (already enabled: not an error to keep)
+  }
   hipIpcMemHandle_t h;
   std::memcpy(&h, handle, sizeof(h));
   void *p = nullptr;

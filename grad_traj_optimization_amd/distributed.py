@@ -26,12 +26,24 @@ one-GPU box); the evaluation itself is injected as `run_bucket_fn(ring_index)`,
 which must enqueue `steps_per_bucket` evaluations writing costs into
 `cost_ring[ring_index][step]` and gradients into `grad_ring[ring_index]`.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from .problem import shard_range  # re-exported: the batch partition rule
 
 __all__ = ["shard_range", "ResultGatherPipeline", "CostGatherPipeline"]
+
+
+def _host_id():
+    """Something two processes share exactly when they run on one machine (boot id; the host name as a fallback)."""
+    try:
+        with open("/proc/sys/kernel/random/boot_id") as f:
+            return f.read().strip()
+    except OSError:
+        import socket
+        return socket.gethostname()
 
 
 class _DeviceBytes:
@@ -86,40 +98,54 @@ class ResultGatherPipeline:
         why = "ok"
         dsts = None
         opened, owned = [], []
+        old = [self.gathered[0], self.gathered[1]] + (list(self.grad_gathered) if self.gather_grads else [])
+        payload, views = None, []
         try:
-            old = [self.gathered[0], self.gathered[1]] + (list(self.grad_gathered) if self.gather_grads else [])
             dev = old[0].device
-            mine, views = [], []
+            mine = []
             for t in old:
                 nbytes = t.numel() * t.element_size()
                 ptr, handle = ctx.shared_alloc(nbytes)
                 owned.append(ptr)
                 mine.append(handle)
                 views.append(torch.as_tensor(_DeviceBytes(ptr, nbytes), device=dev).view(t.dtype).view(t.shape))
-            allh = [None] * self.world
-            dist.all_gather_object(allh, mine)
-            base = []                           # [rank][buffer] -> device address of that rank's buffer in THIS process
-            for r in range(self.world):
-                if r == self.rank:
-                    base.append(list(owned))
-                    continue
-                row = []
-                for h in allh[r]:
-                    p = ctx.shared_open(h)
-                    opened.append(p)
-                    row.append(p)
-                base.append(row)
-            es = old[0].element_size()
-            cost_bytes = self.G * self.cost_ring[0].shape[1] * es
-            dsts = {"cost": [[base[r][j] + self.rank * cost_bytes for r in range(self.world)] for j in range(2)],
-                    "cost_bytes": cost_bytes}
-            if self.gather_grads:
-                gb = self.grad_ring[0].numel() * es
-                dsts["grad"] = [[base[r][2 + j] + self.rank * gb for r in range(self.world)] for j in range(2)]
-                dsts["grad_bytes"] = gb
-        except Exception as e:                  # (a handle that cannot be opened, no peer access, ...)
-            why = f"mapping the peers' buffers failed: {e!r}"
-            dsts = None
+            payload = (int(ctx.device), mine, _host_id())
+        except Exception as e:
+            why = f"allocating shareable buffers failed: {e!r}"
+        allh = [None] * self.world
+        dist.all_gather_object(allh, payload)   # (every rank takes part, whatever happened above)
+        if any(h is None for h in allh):
+            if payload is not None:
+                why = "another rank could not allocate its buffers"
+        elif any(h[2] != allh[self.rank][2] for h in allh):          # (one node: every process counts the devices alike)
+            why = "the ranks run on several hosts: buffers can only be mapped within one"
+        else:
+            try:
+                if os.environ.get("GTOP_PUSH_FORCE_FAIL") == str(self.rank):     # (tests: the fallback must hold on every rank)
+                    raise RuntimeError("forced by GTOP_PUSH_FORCE_FAIL")
+                base = []                       # [rank][buffer] -> device address of that rank's buffer in THIS process
+                for r in range(self.world):
+                    if r == self.rank:
+                        base.append(list(owned))
+                        continue
+                    row = []
+                    owner_dev, handles, _ = allh[r]
+                    for h in handles:
+                        p = ctx.shared_open(h, owner_dev)
+                        opened.append(p)
+                        row.append(p)
+                    base.append(row)
+                es = old[0].element_size()
+                cost_bytes = self.G * self.cost_ring[0].shape[1] * es
+                dsts = {"cost": [[base[r][j] + self.rank * cost_bytes for r in range(self.world)] for j in range(2)],
+                        "cost_bytes": cost_bytes}
+                if self.gather_grads:
+                    gb = self.grad_ring[0].numel() * es
+                    dsts["grad"] = [[base[r][2 + j] + self.rank * gb for r in range(self.world)] for j in range(2)]
+                    dsts["grad_bytes"] = gb
+            except Exception as e:              # (a handle that cannot be opened, no peer access, ...)
+                why = f"mapping the peers' buffers failed: {e!r}"
+                dsts = None
         # probe: every rank pushes a rank-coded pattern through the real path; every rank checks every slot
         ok_local = dsts is not None
         saved = (self.gathered, self.grad_gathered)

@@ -505,12 +505,17 @@ int gtop_push_rows(gtop_ctx *ctx, const void *d_src, size_t bytes, void *const *
  * device allocation of its own (an IPC handle names a whole allocation) on the
  * context's device and its 64-byte handle, to be sent to the peers by any means;
  * gtop_shared_open maps a PEER's buffer (a handle made in another process) for
- * the context's device — the device whose kernels will store into it — with lazy
- * peer access; gtop_shared_close unmaps it; gtop_shared_free releases an
+ * the context's device — the device whose kernels will store into it; with
+ * owner_device >= 0 (the owner's device ordinal as THIS process counts devices)
+ * the call first checks hipDeviceCanAccessPeer and enables peer access, and
+ * refuses (GTOP_ERR_STATE) where the owner's device cannot be reached, instead of
+ * leaving a mapping a kernel would fault on; -1 = unknown: the lazy flag alone.
+ * gtop_shared_close unmaps it; gtop_shared_free releases an
  * allocation of gtop_shared_alloc (after the peers have closed it). */
 #define GTOP_IPC_HANDLE_BYTES 64
 int gtop_shared_alloc(gtop_ctx *ctx, size_t bytes, void **d_ptr, unsigned char handle[GTOP_IPC_HANDLE_BYTES]);
-int gtop_shared_open(gtop_ctx *ctx, const unsigned char handle[GTOP_IPC_HANDLE_BYTES], void **d_ptr);
+int gtop_shared_open(gtop_ctx *ctx, const unsigned char handle[GTOP_IPC_HANDLE_BYTES], int owner_device,
+                     void **d_ptr);
 int gtop_shared_close(gtop_ctx *ctx, void *d_ptr);
 int gtop_shared_free(gtop_ctx *ctx, void *d_ptr);
 

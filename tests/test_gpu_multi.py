@@ -119,6 +119,17 @@ def test_bench_self_launches_two_ranks_on_one_card():
     assert r["config"]["buckets"] == 1 and r["config"]["path"] == "collective"
 
 
+@pytest.mark.timeout(900)
+def test_a_rank_that_cannot_map_its_peers_sends_every_rank_to_the_library_gather():
+    """The safety net of the push path: rank 1 fails to map rank 0's buffers (forced); BOTH ranks must then drop the
+    mappings they hold and gather through the process group — the run completes, says which path it took and why."""
+    r = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--batch", "512"],
+               {"GTOP_BENCH_BACKEND": "gloo", "GTOP_BENCH_SHARE_DEVICE": "1", "GTOP_PUSH_FORCE_FAIL": "1"})
+    col = r["collective"]
+    assert col["gather_impl"] == "library" and "rank 1" in col["push_note"] and "GTOP_PUSH_FORCE_FAIL" in col["push_note"]
+    assert r["parity"]["ok"] and r["value"] > 1e4 and r["n_gpus"] == 2
+
+
 def test_two_contexts_on_one_device_equal_the_unsharded_batch(gtop):
     """configs[3] in miniature: contiguous shards on separate contexts (each with its
     own replicated field, built independently) and separate streams, no reduction
