@@ -463,12 +463,17 @@ def main():
         for b in range(nbuckets):
             run_b(b)
         drain()                    # the stream now also waits for the last bucket's all-gather (no host wait yet)
+        ta = time.perf_counter()
         while not stream.query():  # poll: a blocking wait sleeps on an interrupt, tens of us after the last kernel ends
             pass
+        tb = time.perf_counter()
         torch.cuda.synchronize()
         t1 = time.perf_counter()   # this rank's K steps and their collectives are done; the job's time is the MAX over ranks
         barrier()
         st = stamps.tolist()
+        if rank == 0 and os.environ.get("GTOP_BENCH_REGION_SPLIT"):     # diagnostic: where the host's time around the region goes
+            log(f"region split: launch calls {(ta - t0) * 1e6:.1f} us, poll {(tb - ta) * 1e6:.1f}, synchronize {(t1 - tb) * 1e6:.1f}, "
+                f"total {(t1 - t0) * 1e6:.1f}; device span {(st[1] - st[0]) / clock_hz * 1e6:.1f}")
         return t1 - t0, (st[1] - st[0]) / clock_hz
 
     # Collective runs: one untimed rehearsal of the whole bracket first (declared in `config`).  The first region of a
