@@ -476,12 +476,13 @@ def main():
                 f"total {(t1 - t0) * 1e6:.1f}; device span {(st[1] - st[0]) / clock_hz * 1e6:.1f}")
         return t1 - t0, (st[1] - st[0]) / clock_hz
 
-    # Collective runs: one untimed rehearsal of the whole bracket first (declared in `config`).  The first region of a
-    # process is not like the others — with RCCL's captured all-gather in the buckets it read 170-290 us where every later
-    # one reads 114 (world size 1, tools/calls/call_r4_26.sh), its 20 kernels themselves spread over 140-250 us — a
-    # one-time cost of the communication library's first synchronised use, like the graphs' upload, not a step's.
+    # One untimed rehearsal of the whole bracket first (declared in `config`, like the clock warm-up).  The first region
+    # of a process is not like the others: with RCCL's captured all-gather in the buckets it read 170-290 us where every
+    # later one reads 114 (world size 1, tools/calls/call_r4_26.sh), its 20 kernels themselves spread over 140-250 us;
+    # on the single path its launch call takes 28 us where every later one takes 14 (109 against 98 us for the region,
+    # call_r4_31) — one-time costs of the bracket's first use, like the graphs' upload, not a step's.
     region_rehearsals = 0
-    if collective and os.environ.get("GTOP_BENCH_REHEARSE_REGION", "1") == "1":
+    if os.environ.get("GTOP_BENCH_REHEARSE_REGION", "1") == "1":
         timed_region(run_bucket)
         region_rehearsals = 1
     elapsed, gpu_elapsed = timed_region(run_bucket)

@@ -39,7 +39,7 @@ def test_bench_rank_path_with_rccl_at_world_size_one():
     assert r["parity"]["ok"] and r["value"] > 1e4
     assert r["config"]["gather"] == "point-to-point stores (gtop_push_rows), captured in each bucket's hipGraph"
     assert r["collective"]["gather_impl"] == "push"
-    assert r["config"]["untimed_region_rehearsals"] == 1          # (collective runs only; declared)
+    assert r["config"]["untimed_region_rehearsals"] == 1          # (declared)
     assert r["config"]["path"] == "collective" and r["config"]["buckets"] == 4
     col = r["collective"]
     assert col["backend"] == "nccl" and col["ranks"] == col["rccl_ranks"] == 1
@@ -94,7 +94,7 @@ def test_gpus_1_is_the_single_path_however_it_is_started():
         assert r["config"]["steps_per_bucket"] == 20 and r["config"]["buckets"] == 1 and r["config"]["gather"] == "none"
         assert r["roofline"]["frac_source"] == "timed_region_gpu"
         assert r["config"]["clock_warmup_ms"] == 40.0 and r["config"]["clock_warmup_steps"] >= 20
-        assert r["config"]["untimed_region_rehearsals"] == 0
+        assert r["config"]["untimed_region_rehearsals"] == 1
         f = r["roofline"]["frac_by_source"]
         assert abs(f["timed_region_gpu"] - f["probe"]) <= 0.08 * f["probe"], f      # two clocks, one kernel
         assert abs(r["roofline"]["frac"] - f["timed_region_gpu"]) < 1e-12
