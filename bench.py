@@ -307,12 +307,12 @@ def main():
     stamps = STAMP_INIT.clone()          # [earliest, latest] device-clock stamp since the last reset
     clock_hz = ctx.clock_hz()
 
-    def run_bucket_eager(j, steps=None, stamp=True):
+    def run_bucket_eager(j, steps=None, stamp=True, tail_stamp=True):
         if stamp:
             ctx.clock_stamp(stamps)
         for s in range(G if steps is None else steps):
             ctx.eval_device(x, Df, T, pipe.cost_ring[j][s], pipe.grad_ring[j])
-        if stamp:
+        if stamp and tail_stamp:
             ctx.clock_stamp(stamps)     # behind the last kernel, in front of the bucket's all-gather
 
     def run_bucket_graph(j):
@@ -336,9 +336,14 @@ def main():
                 gph = torch.cuda.CUDAGraph()
                 # thread_local: a HIP call from another thread (RCCL's watchdog) must not break the capture
                 with torch.cuda.graph(gph, capture_error_mode="thread_local"):
-                    run_bucket_eager(j)
-                    if with_gather:
-                        pipe.gather_now(j)
+                    if with_gather and push_mode:
+                        # the gather kernel takes the bucket's closing clock stamp itself as it starts: a node saved
+                        run_bucket_eager(j, tail_stamp=False)
+                        pipe.gather_now(j, clock_minmax=stamps)
+                    else:
+                        run_bucket_eager(j)
+                        if with_gather:
+                            pipe.gather_now(j)
                 gs.append(gph)
             return gs
         # with a collective (RCCL only): first try to capture the bucket's all-gather INTO its graph, behind the last
@@ -378,6 +383,9 @@ def main():
     if rank == 0:
         log(f"launch mode {launch_mode}, {G} steps per bucket x {nbuckets}, backend {backend if collective else 'none'}")
     run_bucket, drain = pipe.run_bucket, pipe.drain
+    if graphs is not None and pipe.gather_in_bucket_fn:
+        def run_bucket(b):                # (nothing pending on the host in this form: straight to the graph)
+            graphs[(b & 1) % len(graphs)].replay()
 
     def barrier():
         if collective:
@@ -457,6 +465,14 @@ def main():
         barrier()
         torch.cuda.synchronize()
         if start_at is not None and 0.0 < start_at - time.perf_counter() < 0.01:   # (another node's clock, a slow barrier: start now)
+            # the wait for the common instant, with the GPU kept at work: three idle milliseconds let the card's clocks sag
+            # (the region's kernels then read 4.0-4.1 us where the single path, which has no such gap, reads 3.75)
+            if kernel_graphs is not None and os.environ.get("GTOP_BENCH_BUSY_WAIT", "1") == "1":
+                while start_at - time.perf_counter() > 400e-6:
+                    kernel_graphs[0].replay()
+                    torch.cuda.synchronize()
+                stamps.copy_(STAMP_INIT)
+                torch.cuda.synchronize()
             while time.perf_counter() < start_at:
                 pass
         t0 = time.perf_counter()

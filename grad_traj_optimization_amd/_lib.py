@@ -126,7 +126,7 @@ def load_library():
         "gtop_update_sdf_map_window_device": (C.c_int, [vp, dp, dp, vp, C.c_int, vp]),
         "gtop_set_field_precisions": (C.c_int, [vp, C.c_int]),
         "gtop_device_clock_stamp": (C.c_int, [vp, vp, vp]),
-        "gtop_push_rows": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, vp]),
+        "gtop_push_rows": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, vp, vp]),
         "gtop_shared_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p]),
         "gtop_shared_open": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
         "gtop_shared_close": (C.c_int, [vp, vp]),
@@ -356,7 +356,7 @@ class GtopContext:
         """False: keep fp64 corner records only (the capturable map updates then skip the fp32 pass; fp32 evaluations fail)."""
         self._chk(self._L.gtop_set_field_precisions(self._h, 1 if keep_fp32 else 0))
 
-    def push_rows(self, src, dst_ptrs, nbytes=None, stream=None):
+    def push_rows(self, src, dst_ptrs, nbytes=None, stream=None, clock_minmax=None):
         """ONE kernel copies `src` (a contiguous CUDA tensor, or its first nbytes) to every device address in dst_ptrs
         (ints: slots in this process's and in peers' mapped buffers) — gtop_push_rows, the all-gather as stores."""
         import torch
@@ -367,6 +367,7 @@ class GtopContext:
             stream = torch.cuda.current_stream(src.device).cuda_stream
         arr = (C.c_void_p * len(dst_ptrs))(*[int(p) for p in dst_ptrs])
         self._chk(self._L.gtop_push_rows(self._h, C.c_void_p(src.data_ptr()), int(nbytes), arr, len(dst_ptrs),
+                                         C.c_void_p(clock_minmax.data_ptr()) if clock_minmax is not None else None,
                                          C.c_void_p(stream)))
 
     def shared_alloc(self, nbytes):

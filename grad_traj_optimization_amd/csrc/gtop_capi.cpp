@@ -1163,11 +1163,12 @@ int gtop_device_clock_stamp(gtop_ctx *c, void *d_minmax, void *hip_stream) try {
 } GTOP_CATCH_STATUS(c)
 
 // ---- SURVEY 8e's collective as point-to-point stores (gtop_push.hip) ----
-int gtop_push_rows(gtop_ctx *c, const void *d_src, size_t bytes, void *const *d_dsts, int n_dsts, void *hip_stream) try {
+int gtop_push_rows(gtop_ctx *c, const void *d_src, size_t bytes, void *const *d_dsts, int n_dsts, void *d_clock_minmax,
+                   void *hip_stream) try {
   if (!c) return GTOP_ERR_INVALID;
   if (n_dsts < 0 || n_dsts > GTOP_PUSH_MAX_DSTS || (bytes > 0 && n_dsts > 0 && (!d_src || !d_dsts)))
     return fail(c, GTOP_ERR_INVALID, "push_rows: 0 .. 16 destinations, non-NULL buffers");
-  if (bytes == 0 || n_dsts == 0) return GTOP_OK;
+  if ((bytes == 0 || n_dsts == 0) && !d_clock_minmax) return GTOP_OK;
   GtopPushDsts dsts{};
   if (reinterpret_cast<uintptr_t>(d_src) & 15u) return fail(c, GTOP_ERR_INVALID, "push_rows: source not 16-byte aligned");
   for (int k = 0; k < n_dsts; ++k) {
@@ -1176,7 +1177,8 @@ int gtop_push_rows(gtop_ctx *c, const void *d_src, size_t bytes, void *const *d_
     dsts.p[k] = d_dsts[k];
   }
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, gtop_launch_push_rows(d_src, bytes, dsts, n_dsts, static_cast<hipStream_t>(hip_stream)));
+  HIPCHK(c, gtop_launch_push_rows(d_src, bytes, dsts, n_dsts, static_cast<unsigned long long *>(d_clock_minmax),
+                                  static_cast<hipStream_t>(hip_stream)));
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)
 

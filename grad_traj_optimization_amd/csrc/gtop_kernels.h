@@ -80,7 +80,8 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &p
 // this process; 16-byte aligned), one kernel: gtop_push.hip
 #define GTOP_PUSH_MAX_DSTS 16
 struct GtopPushDsts { void *p[GTOP_PUSH_MAX_DSTS]; };
-hipError_t gtop_launch_push_rows(const void *src, size_t bytes, const GtopPushDsts &dsts, int n_dsts, hipStream_t stream);
+hipError_t gtop_launch_push_rows(const void *src, size_t bytes, const GtopPushDsts &dsts, int n_dsts,
+                                 unsigned long long *minmax /* optional clock stamp, NULL = none */, hipStream_t stream);
 
 // minmax[0] = min(minmax[0], clock), minmax[1] = max(minmax[1], clock) of the device's constant-rate wall clock
 hipError_t gtop_launch_clock_stamp(unsigned long long *minmax, hipStream_t stream);

@@ -18,7 +18,15 @@ namespace {
 
 typedef unsigned int gtop_u4 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256) push_rows_kernel(const unsigned char *__restrict__ src, size_t bytes, GtopPushDsts d) {
+__global__ void __launch_bounds__(256) push_rows_kernel(const unsigned char *__restrict__ src, size_t bytes, GtopPushDsts d,
+                                                        unsigned long long *minmax) {
+  // optionally the device-clock stamp of gtop_device_clock_stamp, taken as the kernel starts: "behind the last
+  // evaluation, in front of the gather" without a kernel of its own (a node of a graph costs its 1.7 us floor)
+  if (minmax && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned long long t = wall_clock64();
+    atomicMin(minmax, t);
+    atomicMax(minmax + 1, t);
+  }
   unsigned char *dst = static_cast<unsigned char *>(d.p[blockIdx.y]);   // one destination per grid row: the links work side by side
   const size_t nvec = bytes >> 4;
   const size_t stride = (size_t)gridDim.x * 256;
@@ -29,14 +37,15 @@ __global__ void __launch_bounds__(256) push_rows_kernel(const unsigned char *__r
 
 }  // namespace
 
-hipError_t gtop_launch_push_rows(const void *src, size_t bytes, const GtopPushDsts &dsts, int n_dsts, hipStream_t stream) {
-  if (bytes == 0 || n_dsts <= 0) return hipSuccess;
+hipError_t gtop_launch_push_rows(const void *src, size_t bytes, const GtopPushDsts &dsts, int n_dsts,
+                                 unsigned long long *minmax, hipStream_t stream) {
+  if (bytes == 0 || n_dsts <= 0) return minmax ? gtop_launch_clock_stamp(minmax, stream) : hipSuccess;
   if (n_dsts > GTOP_PUSH_MAX_DSTS) return hipErrorInvalidValue;
   // (16-byte accesses: every pointer 16-byte aligned — the C-ABI checks)
   size_t blocks = ((bytes >> 4) + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 256) blocks = 256;      // per destination; a grid-stride loop covers the rest
   hipLaunchKernelGGL(push_rows_kernel, dim3((unsigned)blocks, (unsigned)n_dsts), dim3(256), 0, stream,
-                     static_cast<const unsigned char *>(src), bytes, dsts);
+                     static_cast<const unsigned char *>(src), bytes, dsts, minmax);
   return hipGetLastError();
 }

@@ -232,11 +232,12 @@ class ResultGatherPipeline:
             if self.gather_grads:
                 self._pending[j].append(self._gather(self.grad_gathered[j], self.grad_ring[j]))
 
-    def gather_now(self, j):
-        """The bucket's all-gathers, synchronously on the current stream (for capture into the bucket's graph)."""
+    def gather_now(self, j, clock_minmax=None):
+        """The bucket's all-gathers, synchronously on the current stream (for capture into the bucket's graph).
+        clock_minmax (push path only): the gather kernel also takes the device-clock stamp as it starts."""
         if self._push is not None:
             ctx, d = self._push
-            ctx.push_rows(self.cost_ring[j], d["cost"][j], d["cost_bytes"])
+            ctx.push_rows(self.cost_ring[j], d["cost"][j], d["cost_bytes"], clock_minmax=clock_minmax)
             if self.gather_grads:
                 ctx.push_rows(self.grad_ring[j], d["grad"][j], d["grad_bytes"])
             return

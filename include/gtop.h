@@ -497,10 +497,12 @@ int gtop_set_optimizer_precision(gtop_ctx *ctx, int dtype);
  * alone, so no protocol is needed; an owner may read its buffer after any
  * synchronisation that orders the read behind the writers' kernels (the closing
  * barrier of a timed region).  All pointers 16-byte aligned.  Asynchronous,
- * capturable.  bench.py's N > 1 runs gather their costs this way, with RCCL's
+ * capturable.  d_clock_minmax != NULL: the kernel also takes the device-clock
+ * stamp of gtop_device_clock_stamp as it starts (behind the last evaluation, in
+ * front of the stores) — a node of a graph saved.  bench.py's N > 1 runs gather their costs this way, with RCCL's
  * all-gather as the fallback when the peers' buffers cannot be mapped. */
 int gtop_push_rows(gtop_ctx *ctx, const void *d_src, size_t bytes, void *const *d_dsts, int n_dsts,
-                   void *hip_stream);
+                   void *d_clock_minmax, void *hip_stream);
 /* Buffers for it that another process can map.  gtop_shared_alloc: a zeroed
  * device allocation of its own (an IPC handle names a whole allocation) on the
  * context's device and its 64-byte handle, to be sent to the peers by any means;

@@ -762,6 +762,15 @@ def test_push_rows_copies_to_every_destination(gtop):
         for b in bufs:
             assert torch.equal(b[128:128 + nbytes], src[:nbytes])
             assert bool((b[:128] == 255).all()) and bool((b[128 + nbytes:] == 255).all())     # nothing beyond the rows
+    # with the clock stamp folded in: min <= max, both set, the rows still copied
+    mm = torch.tensor([2 ** 63 - 1, 0], dtype=torch.int64, device=dev)
+    src = torch.arange(256, dtype=torch.uint8, device=dev)
+    dst = torch.zeros(256, dtype=torch.uint8, device=dev)
+    ctx.clock_stamp(mm)
+    ctx.push_rows(src, [dst.data_ptr()], 256, clock_minmax=mm)
+    torch.cuda.synchronize()
+    lo, hi = mm.tolist()
+    assert 0 < lo <= hi < 2 ** 63 - 1 and torch.equal(dst, src)
     src = torch.zeros(64, dtype=torch.uint8, device=dev)
     with pytest.raises(gtop.GtopError):
         ctx.push_rows(src, [src.data_ptr() + 8], 16)                  # misaligned destination
