@@ -264,8 +264,13 @@ def test_random_draw_optimizer(gtop, oracle_mod, seed):
     ctx.set_params(**kw)
     ctx.set_problem(T, Df)
     ctx.set_optimizer_fusion(int(rng.choice([2, 2, 1, 0])))
+    # up to 6 segments: half the draws run the loop with TWO trajectories per wavefront (five lanes per segment: what the
+    # launch rule takes for fp32 evaluations of large batches), the others with one
+    two_per_wave = b.m <= 6 and bool(rng.integers(0, 2))
+    if two_per_wave and not kw.get("enable_dyn"):
+        ctx.set_launch_geometry(0, 6)
     xs, costs, nev, code = ctx.optimize_batch_ex(x0, lb, ub, evals)
-    what = (seed, b.m, B, evals, kw)
+    what = (seed, b.m, B, evals, kw, "two per wavefront" if two_per_wave else "")
     assert np.array_equal(nev[ok], n_ref[ok]), what
     # Same road on EVERY row — or a shown reason (round 4; round 3 excused up to 10 % of the rows of every draw without
     # asking why).  A row that ends elsewhere is re-run through the independent numpy restatement of the algorithm
