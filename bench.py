@@ -43,6 +43,10 @@ import subprocess
 import sys
 import time
 
+# dmabuf IPC (RCCL's transports, and the buffers the ranks map from each other for the push gather) — the pool's driver
+# supports no other kind; set before anything initialises the GPU runtime
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
