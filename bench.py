@@ -109,6 +109,8 @@ def dominant_kernel(m, B, dtype, pinned):
     if pinned:
         return "gtop_eval_wave_kernel (pinned samples per lane)"
     tail = "(anonymous namespace)::GtopNoMma, false, "
+    if dtype == "f32" and m <= 12 and B * m >= 65536 * 6:
+        return f"gtop_eval_wave_kernel<{R}, false, 30, 1, true, 3, {tail}false>"    # one lane per segment, 64 / m trajectories per wavefront
     if m <= 6:
         if B >= (2048 if dtype == "f32" else 4096):
             return f"gtop_eval_wave_kernel<{R}, false, 6, 2, true, 3, {tail}false>"   # two trajectories per wavefront (fp32: packed pairs)

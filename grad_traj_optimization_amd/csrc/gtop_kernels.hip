@@ -683,8 +683,8 @@ struct GtopNoMma {};
 // (the same for the fp64 body that walks more than 12 segments in chunks: 19 spilled registers at 168)
 template <typename R, bool WIDE, typename MM, int SPL, int MINW, bool DYN, bool LONG>
 constexpr int gtop_wave_budget() {
-  return ((!std::is_same<MM, GtopNoMma>::value && SPL == 6) || DYN || ((WIDE || LONG) && sizeof(R) == 8 && SPL == 6) ||
-          (sizeof(R) == 4 && SPL == 6))   // (packed fp32 with the double coefficients of its exact positions: 190 VGPRs)
+  return ((!std::is_same<MM, GtopNoMma>::value && SPL == 6) || DYN || ((WIDE || LONG) && sizeof(R) == 8 && SPL >= 6) ||
+          (sizeof(R) == 4 && SPL >= 6))   // (packed fp32 with the double coefficients of its exact positions: 190 VGPRs)
              ? 2
              : MINW;
 }
@@ -713,7 +713,14 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   constexpr int SPW = 64 / LPS;         // segment slots per wavefront
   constexpr int kStride = NW == 2 ? ((2 * LPS * SPW) | 1) : red_stride(SPL);   // (two wavefronts: 120 busy lanes)
   constexpr int kMVc = (SPL == 6 && NT == 1) ? 128 : 64;   // rows of the optimizer loop's LDS vectors: n <= 45 resp. 99 variables
-  static_assert(SPL == 3 || SPL == 6, "10 or 5 lanes per segment");
+  static_assert(SPL == 3 || SPL == 6 || SPL == 30, "10 or 5 lanes per segment, or one");
+  // MANY (SPL = 30): ONE lane per segment — a lane walks all 30 samples of its segment, so the per-lane set-up
+  // (coefficients, jerk term, A^-T) is paid once per segment instead of five or ten times and no sum over a segment's
+  // lanes is left — and as many whole trajectories per wavefront as fit: nt = 64 / m (10 of 6 segments, 5 of 12).  The
+  // epilogue is a list of nt n + nt tasks dealt over the lanes: a free variable = two tile entries, a trajectory's cost
+  // = its m entries of row 18 added in segment order.  For batches that put several such wavefronts on every SIMD.
+  constexpr bool MANY = SPL == 30;
+  static_assert(!MANY || (NT == 1 && !LONG && !MMA && NW == 1 && MINW >= 3), "one lane per segment: plain evaluation, one sample (pair) at a time");
   static_assert(SPL == 3 || MINW >= 3, "six samples per lane: one (pair) at a time only");
   static_assert(NT == 1 || NT == 2, "one or two trajectories per wavefront");
   static_assert(!LONG || (SPL == 6 && NT == 1), "more than 12 segments: five lanes per segment, one trajectory");
@@ -736,7 +743,8 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   GTOP_STAMP(1);
 
   // XCD-aware order (workgroup id mod 8 = XCD): XCD x gets the x-th contiguous eighth of the batch
-  const int ngroups = (a.B + NT - 1) / NT;
+  const int nt = MANY ? 64 / m : NT;   // trajectories per wavefront
+  const int ngroups = (a.B + nt - 1) / nt;
   const int per_xcd = (ngroups + 7) >> 3;
   // The grid is 8*per_xcd workgroups; the up to 7 beyond the batch take no early exit (a branch here would
   // split the kernel-argument loads into two dependent round trips): they shadow the last group with every
@@ -744,16 +752,20 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   const int grp_raw = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   const bool grp_ok = grp_raw < ngroups;
   const int grp = grp_ok ? grp_raw : ngroups - 1;
-  const int b0 = grp * NT;
+  const int b0 = grp * nt;
 
   const int slot_w = lane / LPS, li = lane - slot_w * LPS;   // segment slot within the wavefront, lane within the segment
   const int slot = wave * SPW + slot_w;
   int tl = 0, s = slot;
-  if constexpr (NT == 2) {
+  if constexpr (MANY) {
+    // slot / m by a 16-bit reciprocal (exact: slot < 64, and slot/m is never within 2^-10 below an integer)
+    tl = (int)(((unsigned)slot * (unsigned)((65536 + m - 1) / m)) >> 16);
+    s -= tl * m;
+  } else if constexpr (NT == 2) {
     tl = s >= m;
     s -= tl * m;
   }
-  bool seg_ok = grp_ok & (slot_w < SPW) & (slot < NT * m) & (b0 + tl < a.B);   // (LONG: set per chunk, below)
+  bool seg_ok = grp_ok & (slot_w < SPW) & (slot < nt * m) & (b0 + tl < a.B);   // (LONG: set per chunk, below)
   if (!seg_ok) { tl = 0; s = 0; }   // idle lanes shadow the first segment: finite data, results never read
 
   unsigned long long t_launch = 0ull;
@@ -841,7 +853,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     }
   }
   [[maybe_unused]] R cost_run = (R)0;   // LONG: this lane's share of the cost over its chunks
-  constexpr int kRounds = LONG ? 1 : (NT * 9 * (NW * SPW / NT - 1) + 64 * NW - 1) / (64 * NW);
+  constexpr int kRounds = (LONG || MANY) ? 1 : (NT * 9 * (NW * SPW / NT - 1) + 64 * NW - 1) / (64 * NW);
   const int tid = NW == 2 ? (int)threadIdx.x : lane;
   int offA[kRounds], offB[kRounds];     // (filled below, while the inputs are on their way)
   bool okq[kRounds];
@@ -886,7 +898,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // the inputs are on their way): free variable = end of segment wpt-1 (entry 2 der + 1) + start of segment
   // wpt (entry 2 der)  (:425-432); tile[v][lane] holds entry v of lane's segment.
 #pragma unroll
-  for (int r = 0; r < (LONG ? 0 : kRounds); ++r) {
+  for (int r = 0; r < ((LONG || MANY) ? 0 : kRounds); ++r) {
     const int qi = tid + 64 * NW * r;
     int tq = 0, i = qi;
     if constexpr (NT == 2) {
@@ -910,7 +922,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   // the same way (a trajectory's result must not depend on its place in the pair).
   const int cs = lane - 48;
   const int ct = NT == 2 ? cs >> 3 : 0, csi = NT == 2 ? cs & 7 : cs;   // trajectory, segment
-  cost_lane = !LONG & (wave == NW - 1) & (cs >= 0) & (csi < m);   // (two wavefronts: the second one's lanes 48 ..)
+  cost_lane = !LONG & !MANY & (wave == NW - 1) & (cs >= 0) & (csi < m);   // (two wavefronts: the second one's lanes 48 ..)
   if (cost_lane) offA[kRounds - 1] = 18 * kStride + (ct * m + csi) * LPS;
   const R ws = a.ws;   // the launcher has applied :412-415 (step 1 -> ws = 0): `step` is not read here
   const R wc = a.wc;
@@ -1350,6 +1362,30 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
     } else {
       if (grp_ok & (lane == 0)) a.cost[b0] = ctot;
     }
+  } else if constexpr (MANY) {
+    // the wavefront's nt n free variables, then its nt costs, dealt over the lanes 64 at a time; trajectory tq's
+    // variable i sits at b0 n + qi with qi = tq n + i: the rows of a wavefront are consecutive, the stores coalesced
+    const int ntn = nt * n, ntasks = ntn + nt;
+    const unsigned inv_n = (unsigned)(((1u << 24) + (unsigned)n - 1u) / (unsigned)n);   // qi / n exactly: qi < 1 024, n <= 567
+    for (int r0 = 0; r0 < ntasks; r0 += 64) {
+      const int qi = r0 + lane;
+      if (qi < ntn) {
+        const int tq = (int)(((unsigned)qi * inv_n) >> 24);
+        const int i = qi - tq * n;
+        const int axis = (i >= ndp) + (i >= 2 * ndp), c = i - axis * ndp;
+        const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
+        const int rowB = axis * 6 + 2 * der, sA = tq * m + wpt - 1;
+        // end of segment wpt-1 (entry 2 der + 1) + start of segment wpt (entry 2 der)  (:425-432)
+        const R gq = (tile[(rowB + 1) * kStride + sA] + tile[rowB * kStride + sA + 1]) + K.eps;
+        if (grp_ok & (b0 + tq < a.B)) a.grad[(size_t)b0 * n + qi] = gq;
+      } else if (qi < ntasks) {
+        const int t = qi - ntn;
+        const R *row = tile + 18 * kStride + t * m;
+        R csum = row[0];
+        for (int sg = 1; sg < m; ++sg) csum += row[sg];     // in segment order, whatever the trajectory's place in the wavefront
+        if (grp_ok & (b0 + t < a.B)) a.cost[b0 + t] = csum + (R)1e-3;   // (:417-418)
+      }
+    }
   } else {
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
@@ -1469,6 +1505,15 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 #ifndef GTOP_OPT_TWO_PER_WAVE_F64_FROM
 #define GTOP_OPT_TWO_PER_WAVE_F64_FROM (1 << 30)
 #endif
+// One lane per segment (SPL = 30, as many trajectories per wavefront as fit) has a quarter fewer instructions per
+// trajectory than five lanes per segment — and four times the distinct 128-byte lines per load instruction (the lanes
+// of an instruction are 64 different segments; five lanes of a segment share a line or two), which is what the vector
+// L1 counts.  Measured (one box, us, launch rule | one lane per segment): fp64 B = 16 384 29.6 | 34.1, 65 536 113.9 |
+// 130.2, 131 072 240 | 259 — never; fp32 (half the loads per sample) 16 384 23.4 | 26.1, 32 768 47.2 | 51.0, 65 536
+// 85.8 | 80.1, 131 072 166 | 135 (-19 %); 12 segments fp32 32 768 82.5 | 79.2.  So: fp32 only, from B x m = 393 216.
+#ifndef GTOP_ONE_LANE_F32_FROM_SEGMENTS
+#define GTOP_ONE_LANE_F32_FROM_SEGMENTS (65536LL * 6)
+#endif
 #ifndef GTOP_TWO_WAVES_UP_TO
 #define GTOP_TWO_WAVES_UP_TO 1024   // trajectories of 7 .. 12 segments: two wavefronts each up to this batch (2 048 wavefronts)
 #endif
@@ -1493,11 +1538,24 @@ static size_t wave_lds_bytes(const GtopEvalPlan &p, int m, size_t elem, bool mma
 // per segment take over (fp32: packed sample pairs).  7 .. 12 segments: five lanes per segment, one
 // trajectory per wavefront.  Past 12: the same wavefront walks the segments 12 at a time (LONG).  The optimizer loop
 // follows the same rule with its own switch points (elem: the precision of its evaluations).  pinned_spl = 3 or 6 overrides the lanes-per-segment choice where it can
-// be honoured (3: up to 6 segments).
+// be honoured (3: up to 6 segments; 30 = one lane per segment: up to 12 segments, plain evaluations; by itself the rule
+// takes it for fp32 batches of 65 536 six-segment trajectories and more).
 bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimizer, GtopEvalPlan *plan) {
-  if (m < 2 || (pinned_spl != 0 && pinned_spl != 3 && pinned_spl != 6)) return false;
+  if (m < 2 || (pinned_spl != 0 && pinned_spl != 3 && pinned_spl != 6 && pinned_spl != 30)) return false;
   GtopEvalPlan p{};
   p.nw = 1;
+  // one lane per segment (SPL = 30; the kernel's MANY): trajectories of up to 12 segments, 64 / m of them per wavefront,
+  // plain evaluation only — for batches that put several such wavefronts on every SIMD
+  const bool many_ok = m <= 12 && !for_optimizer;
+  if (pinned_spl == 30 && !many_ok) return false;
+  if (many_ok && (pinned_spl == 30 || (pinned_spl == 0 && elem == 4 && (long long)B * m >= GTOP_ONE_LANE_F32_FROM_SEGMENTS))) {
+    p.spl = 30;
+    p.nt = 64 / m;
+    p.is_long = false;
+    if (wave_lds_bytes(p, m, elem, false) > 160u * 1024u) return false;
+    *plan = p;
+    return true;
+  }
   // (two trajectories per wavefront at five lanes per segment amortise the per-lane set-up — coefficients, jerk term,
   // A^-T — over six samples instead of three: fewer instructions per trajectory, longer chains per wavefront; it wins
   // once the batch puts several wavefronts on every SIMD.  Round 4, corner records and the sample's loads issued
@@ -1545,6 +1603,10 @@ template <typename R, bool WIDE, typename MM>
 static WaveKernelFn<R, MM> pick_geometry(const GtopEvalPlan &p, int B, bool colli, bool dyn) {
   constexpr bool MMA = !std::is_same<MM, GtopNoMma>::value;
   if (p.is_long) return pick_body<R, WIDE, 6, 1, 3, MM, true>(colli, dyn);
+  if (p.spl == 30) {
+    if constexpr (MMA) return nullptr;   // (the optimizer loop: one or two trajectories per wavefront)
+    else return pick_body<R, WIDE, 30, 1, 3, MM, false>(colli, dyn);
+  }
   if constexpr (!MMA) {
     if (p.nw == 2) return pick_body<R, WIDE, 3, 1, 2, MM, false, 2>(colli, dyn);   // (small batches only: the latency structure)
   }
@@ -1628,14 +1690,14 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &p
 // the optimizer loop: st.iters evaluations at st.xcur, each followed by the CCSA-MMA update, in one launch (fp64)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
                                 bool dyn, hipStream_t stream) {
-  if (plan.nw != 1 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
+  if (plan.nw != 1 || plan.spl == 30 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
   return launch_wave<double, GtopMmaState>(args, st, plan, dyn, stream);
 }
 // the same loop with the evaluations in fp32 on the fp32 field: args.Df / args.T still point at fp64 rows (the state,
 // the bounds, the update and the results are fp64; see the kernel's `In`), args.x / cost / grad are not read
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<float> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
                                 bool dyn, hipStream_t stream) {
-  if (plan.nw != 1 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
+  if (plan.nw != 1 || plan.spl == 30 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
   return launch_wave<float, GtopMmaState>(args, st, plan, dyn, stream);
 }
 

@@ -456,6 +456,12 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
  *       at the evaluation.
  *   6   five lanes per segment: two trajectories of up to 6 segments per
  *       wavefront, one of up to 12, or 12 segments at a time beyond that.
+ *   30  ONE lane per segment (a lane walks all 30 samples), 64 / m whole
+ *       trajectories per wavefront; up to 12 segments, plain evaluations (the
+ *       batched optimizer keeps its own rule); more segments: GTOP_ERR_INVALID
+ *       at the evaluation.  Fewest instructions per trajectory, most distinct
+ *       cache lines per load: the rule takes it for fp32 batches of 65 536
+ *       six-segment trajectories and more.
  *   0   choose from B, m and dtype (measured rule).
  * Other values are GTOP_ERR_INVALID at the call.  Results do not depend on the
  * geometry beyond fp summation order. */

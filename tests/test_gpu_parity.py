@@ -151,11 +151,11 @@ def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, wave
 
 
 def test_launch_geometry_values(gtop):
-    """One kernel family: a workgroup is one wavefront; samples per lane 0, 3 or 6."""
+    """One kernel family: a workgroup is one wavefront; samples per lane 0, 3, 6 or 30."""
     ctx = gtop.GtopContext(device=0)
-    for waves, spl in ((0, 0), (1, 3), (1, 6), (0, 6)):
+    for waves, spl in ((0, 0), (1, 3), (1, 6), (0, 6), (0, 30)):
         ctx.set_launch_geometry(waves, spl)
-    for waves, spl in ((2, 3), (4, 0), (0, 1), (0, 5), (0, 15), (0, 30), (-1, 0)):
+    for waves, spl in ((2, 3), (4, 0), (0, 1), (0, 5), (0, 15), (0, 10), (-1, 0)):
         with pytest.raises(gtop.GtopError) as e:
             ctx.set_launch_geometry(waves, spl)
         assert e.value.code == 1
@@ -179,7 +179,7 @@ def test_parity_wide_index_field(gtop, oracle_mod):
     sdf = oracle_mod.Sdf(origin, res, grid, dist)
     ctx.set_params()
     ctx.set_problem(b.T, b.Df)
-    for spl in (3, 6):
+    for spl in (3, 6, 30):
         ctx.set_launch_geometry(0, spl)
         c, g = ctx.eval_batch(b.x)
         c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params())

@@ -29,5 +29,7 @@ for spec in sys.argv[1:]:
     Df = torch.tensor(b.Df.reshape(-1, 18), dtype=td, device=dev)
     T = torch.tensor(b.T, dtype=td, device=dev)
     ctx.set_params(**prm)
+    SPL = int(os.environ.get("GTOP_SPL", "0"))      # pinned samples per lane (0 = the launch rule)
+    ctx.set_launch_geometry(0, SPL)
     us = _time_evals(ctx, x, Df, T, 600)
-    print(f"B={B:6d} m={m:3d} {dt} {'dyn' if prm else '   '} g{GRID} spl=0: {us:8.2f} us", flush=True)
+    print(f"B={B:6d} m={m:3d} {dt} {'dyn' if prm else '   '} g{GRID} spl={SPL}: {us:8.2f} us", flush=True)
