@@ -111,6 +111,8 @@ def dominant_kernel(m, B, dtype, pinned):
     tail = "(anonymous namespace)::GtopNoMma, false, "
     if dtype == "f32" and m <= 12 and B * m >= 65536 * 6:
         return f"gtop_eval_wave_kernel<{R}, false, 30, 1, true, 3, {tail}false>"    # one lane per segment, 64 / m trajectories per wavefront
+    if m <= 10 and m != 6 and B >= (8192 if m <= 5 else 4096):
+        return f"gtop_eval_wave_kernel<{R}, false, 10, 1, true, 3, {tail}false>"    # three lanes per segment, 21 / m trajectories per wavefront
     if m <= 6:
         if B >= (2048 if dtype == "f32" else 4096):
             return f"gtop_eval_wave_kernel<{R}, false, 6, 2, true, 3, {tail}false>"   # two trajectories per wavefront (fp32: packed pairs)

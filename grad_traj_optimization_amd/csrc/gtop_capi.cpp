@@ -86,7 +86,7 @@ struct gtop_ctx {
   size_t cap_mma_vec = 0, cap_mma_scal = 0, cap_mma_int = 0, cap_mma_f = 0, cap_mma_g = 0, cap_mma_lb = 0,
          cap_mma_ub = 0;
 
-  int spl = 0;     // samples per lane: 0 = auto, 3, 6 or 30 (gtop_set_launch_geometry)
+  int spl = 0;     // samples per lane: 0 = auto, 3, 6, 10 or 30 (gtop_set_launch_geometry)
   int opt_dtype = GTOP_F64;   // gtop_set_optimizer_precision: the arithmetic of the evaluations inside the batched optimizer
   int fuse_mma = 2;         // optimizer: 0 separate update launch, 1 update fused into the evaluation kernel,
                             //            2 (default) the whole loop in one launch (tuning/debug knob)
@@ -978,7 +978,7 @@ int gtop_optimize_device_ex(gtop_ctx *c, int B, int m, void *d_x, const void *d_
   GtopEvalPlan plan;
   const bool f32 = c->opt_dtype == GTOP_F32;   // gtop_set_optimizer_precision: see below
   const size_t eval_elem = f32 ? sizeof(float) : sizeof(double);
-  const int opt_spl = c->spl == 30 ? 0 : c->spl;   // (one lane per segment is a plain-evaluation geometry)
+  const int opt_spl = (c->spl == 30 || c->spl == 10) ? 0 : c->spl;   // (three lanes / one lane per segment: plain-evaluation geometries)
   bool planned = gtop_eval_plan(B, m, eval_elem, opt_spl, /*for_optimizer=*/true, &plan);
   // (two trajectories per wavefront with the velocity / acceleration block compiled in: the fp32 loop would spill —
   // enable_dyn keeps the loop at ten lanes per segment, one trajectory per wavefront)
@@ -1290,10 +1290,11 @@ int gtop_set_launch_geometry(gtop_ctx *c, int waves, int samples_per_lane) try {
   // one kernel family: a workgroup is one wavefront; the lanes-per-segment choice is what is left to pin
   if (waves != 0 && waves != 1) return fail(c, GTOP_ERR_INVALID, "waves per workgroup must be 0 (auto) or 1");
   const int s = samples_per_lane;
-  if (s != 0 && s != 3 && s != 6 && s != 30)
+  if (s != 0 && s != 3 && s != 6 && s != 10 && s != 30)
     return fail(c, GTOP_ERR_INVALID, "samples per lane must be 0 (auto), 3 (ten lanes per segment, up to 6 segments), "
-                                     "6 (five lanes per segment) or 30 (one lane per segment, up to 12 segments; plain "
-                                     "evaluations only: the optimizer loop keeps its own rule)");
+                                     "6 (five lanes per segment), 10 (three lanes per segment, up to 10 segments) or 30 "
+                                     "(one lane per segment, up to 12 segments); 10 and 30 serve plain evaluations only: "
+                                     "the optimizer loop keeps its own rule");
   c->spl = s;
   return GTOP_OK;
 } GTOP_CATCH_STATUS(c)

@@ -713,13 +713,14 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   constexpr int SPW = 64 / LPS;         // segment slots per wavefront
   constexpr int kStride = NW == 2 ? ((2 * LPS * SPW) | 1) : red_stride(SPL);   // (two wavefronts: 120 busy lanes)
   constexpr int kMVc = (SPL == 6 && NT == 1) ? 128 : 64;   // rows of the optimizer loop's LDS vectors: n <= 45 resp. 99 variables
-  static_assert(SPL == 3 || SPL == 6 || SPL == 30, "10 or 5 lanes per segment, or one");
+  static_assert(SPL == 3 || SPL == 6 || SPL == 10 || SPL == 30, "10 or 5 lanes per segment; three or one with as many trajectories per wavefront as fit");
   // MANY (SPL = 30): ONE lane per segment — a lane walks all 30 samples of its segment, so the per-lane set-up
   // (coefficients, jerk term, A^-T) is paid once per segment instead of five or ten times and no sum over a segment's
   // lanes is left — and as many whole trajectories per wavefront as fit: nt = 64 / m (10 of 6 segments, 5 of 12).  The
   // epilogue is a list of nt n + nt tasks dealt over the lanes: a free variable = two tile entries, a trajectory's cost
   // = its m entries of row 18 added in segment order.  For batches that put several such wavefronts on every SIMD.
-  constexpr bool MANY = SPL == 30;
+  // (SPL = 10: the same with three lanes per segment — 21 segment slots: 3 trajectories of up to 7 segments)
+  constexpr bool MANY = SPL == 30 || SPL == 10;
   static_assert(!MANY || (NT == 1 && !LONG && !MMA && NW == 1 && MINW >= 3), "one lane per segment: plain evaluation, one sample (pair) at a time");
   static_assert(SPL == 3 || MINW >= 3, "six samples per lane: one (pair) at a time only");
   static_assert(NT == 1 || NT == 2, "one or two trajectories per wavefront");
@@ -743,7 +744,7 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
   GTOP_STAMP(1);
 
   // XCD-aware order (workgroup id mod 8 = XCD): XCD x gets the x-th contiguous eighth of the batch
-  const int nt = MANY ? 64 / m : NT;   // trajectories per wavefront
+  const int nt = MANY ? SPW / m : NT;   // trajectories per wavefront
   const int ngroups = (a.B + nt - 1) / nt;
   const int per_xcd = (ngroups + 7) >> 3;
   // The grid is 8*per_xcd workgroups; the up to 7 beyond the batch take no early exit (a branch here would
@@ -1376,13 +1377,14 @@ gtop_eval_wave_kernel(const R *__restrict__ arg_x, const R *__restrict__ arg_Df,
         const int wpt = c / 3 + 1, der = c - 3 * (wpt - 1);   // interior waypoint 1..m-1
         const int rowB = axis * 6 + 2 * der, sA = tq * m + wpt - 1;
         // end of segment wpt-1 (entry 2 der + 1) + start of segment wpt (entry 2 der)  (:425-432)
-        const R gq = (tile[(rowB + 1) * kStride + sA] + tile[rowB * kStride + sA + 1]) + K.eps;
+        const R gq = (tree_sum<R, LPS>(tile + (rowB + 1) * kStride + sA * LPS) +
+                      tree_sum<R, LPS>(tile + rowB * kStride + (sA + 1) * LPS)) + K.eps;
         if (grp_ok & (b0 + tq < a.B)) a.grad[(size_t)b0 * n + qi] = gq;
       } else if (qi < ntasks) {
         const int t = qi - ntn;
-        const R *row = tile + 18 * kStride + t * m;
-        R csum = row[0];
-        for (int sg = 1; sg < m; ++sg) csum += row[sg];     // in segment order, whatever the trajectory's place in the wavefront
+        const R *row = tile + 18 * kStride + t * m * LPS;
+        R csum = tree_sum<R, LPS>(row);
+        for (int sg = 1; sg < m; ++sg) csum += tree_sum<R, LPS>(row + sg * LPS);   // in segment order, whatever the trajectory's place in the wavefront
         if (grp_ok & (b0 + t < a.B)) a.cost[b0 + t] = csum + (R)1e-3;   // (:417-418)
       }
     }
@@ -1511,6 +1513,12 @@ bool gtop_field_is_narrow(int nx, int ny, int nz, size_t elem) {
 // L1 counts.  Measured (one box, us, launch rule | one lane per segment): fp64 B = 16 384 29.6 | 34.1, 65 536 113.9 |
 // 130.2, 131 072 240 | 259 — never; fp32 (half the loads per sample) 16 384 23.4 | 26.1, 32 768 47.2 | 51.0, 65 536
 // 85.8 | 80.1, 131 072 166 | 135 (-19 %); 12 segments fp32 32 768 82.5 | 79.2.  So: fp32 only, from B x m = 393 216.
+#ifndef GTOP_THREE_LANES_SHORT_FROM   // three lanes per segment: 2 .. 5 segments from this batch, 7 .. 10 from that
+#define GTOP_THREE_LANES_SHORT_FROM 8192
+#endif
+#ifndef GTOP_THREE_LANES_MID_FROM
+#define GTOP_THREE_LANES_MID_FROM 4096
+#endif
 #ifndef GTOP_ONE_LANE_F32_FROM_SEGMENTS
 #define GTOP_ONE_LANE_F32_FROM_SEGMENTS (65536LL * 6)
 #endif
@@ -1541,13 +1549,33 @@ static size_t wave_lds_bytes(const GtopEvalPlan &p, int m, size_t elem, bool mma
 // be honoured (3: up to 6 segments; 30 = one lane per segment: up to 12 segments, plain evaluations; by itself the rule
 // takes it for fp32 batches of 65 536 six-segment trajectories and more).
 bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimizer, GtopEvalPlan *plan) {
-  if (m < 2 || (pinned_spl != 0 && pinned_spl != 3 && pinned_spl != 6 && pinned_spl != 30)) return false;
+  if (m < 2 || (pinned_spl != 0 && pinned_spl != 3 && pinned_spl != 6 && pinned_spl != 10 && pinned_spl != 30)) return false;
   GtopEvalPlan p{};
   p.nw = 1;
   // one lane per segment (SPL = 30; the kernel's MANY): trajectories of up to 12 segments, 64 / m of them per wavefront,
   // plain evaluation only — for batches that put several such wavefronts on every SIMD
   const bool many_ok = m <= 12 && !for_optimizer;
   if (pinned_spl == 30 && !many_ok) return false;
+  // three lanes per segment (SPL = 10): 21 segment slots per wavefront, 21 / m whole trajectories of up to 10 segments.
+  // Five lanes per segment hold 12 slots — two trajectories of up to 6 segments or one of up to 12 — and leave most of a
+  // wavefront idle for every length but 6, 11 and 12 (busy lanes, five | three per segment: m = 2: 20 | 60, 3: 30 | 63,
+  // 4: 40 | 60, 5: 50 | 60, 6: 60 | 54, 7: 35 | 63, 8: 40 | 48, 9: 45 | 54, 10: 50 | 60, 11: 55 | 33, 12: 60 | 36).
+  // Measured (one box, us, launch rule of before | three lanes per segment), B = 16 384 fp64: m = 2 27.1 | 13.3, 3 27.5 |
+  // 18.5, 4 28.1 | 24.2, 5 29.1 | 25.5; fp32: 3 22.6 | 14.9, 4 22.8 | 18.4, 5 23.1 | 19.2; B = 8 192 fp64: 7 26.7 | 18.6,
+  // 8 27.0 | 23.4, 9 27.2 | 23.7, 10 27.7 | 24.2; fp32: 7 21.7 | 14.7, 8 21.9 | 17.9, 10 22.1 | 18.3; B = 4 096: m = 4
+  // 9.1 | 9.5, 7 14.6 | 12.9, 10 15.1 | 13.8 (fp32 7: 11.2 | 9.6); B = 3 072, m = 8: 11.5 | 12.4; 2 048: alike.
+  const bool three_ok = m <= 10 && !for_optimizer;
+  if (pinned_spl == 10 && !three_ok) return false;
+  const bool three_auto = pinned_spl == 0 && three_ok && m != 6 &&
+                          B >= (m <= 5 ? GTOP_THREE_LANES_SHORT_FROM : GTOP_THREE_LANES_MID_FROM);
+  if (three_ok && (pinned_spl == 10 || three_auto) && !(pinned_spl == 0 && many_ok && elem == 4 &&
+                                                        (long long)B * m >= GTOP_ONE_LANE_F32_FROM_SEGMENTS)) {
+    p.spl = 10;
+    p.nt = 21 / m;
+    p.is_long = false;
+    *plan = p;
+    return true;
+  }
   if (many_ok && (pinned_spl == 30 || (pinned_spl == 0 && elem == 4 && (long long)B * m >= GTOP_ONE_LANE_F32_FROM_SEGMENTS))) {
     p.spl = 30;
     p.nt = 64 / m;
@@ -1606,6 +1634,10 @@ static WaveKernelFn<R, MM> pick_geometry(const GtopEvalPlan &p, int B, bool coll
   if (p.spl == 30) {
     if constexpr (MMA) return nullptr;   // (the optimizer loop: one or two trajectories per wavefront)
     else return pick_body<R, WIDE, 30, 1, 3, MM, false>(colli, dyn);
+  }
+  if (p.spl == 10) {
+    if constexpr (MMA) return nullptr;
+    else return pick_body<R, WIDE, 10, 1, 3, MM, false>(colli, dyn);
   }
   if constexpr (!MMA) {
     if (p.nw == 2) return pick_body<R, WIDE, 3, 1, 2, MM, false, 2>(colli, dyn);   // (small batches only: the latency structure)
@@ -1690,14 +1722,14 @@ hipError_t gtop_launch_eval(const GtopKernelArgs<R> &args, const GtopEvalPlan &p
 // the optimizer loop: st.iters evaluations at st.xcur, each followed by the CCSA-MMA update, in one launch (fp64)
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<double> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
                                 bool dyn, hipStream_t stream) {
-  if (plan.nw != 1 || plan.spl == 30 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
+  if (plan.nw != 1 || plan.spl == 30 || plan.spl == 10 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
   return launch_wave<double, GtopMmaState>(args, st, plan, dyn, stream);
 }
 // the same loop with the evaluations in fp32 on the fp32 field: args.Df / args.T still point at fp64 rows (the state,
 // the bounds, the update and the results are fp64; see the kernel's `In`), args.x / cost / grad are not read
 hipError_t gtop_launch_eval_mma(const GtopKernelArgs<float> &args, const GtopMmaState &st, const GtopEvalPlan &plan,
                                 bool dyn, hipStream_t stream) {
-  if (plan.nw != 1 || plan.spl == 30 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
+  if (plan.nw != 1 || plan.spl == 30 || plan.spl == 10 || (plan.nt != 1 && !(plan.nt == 2 && plan.spl == 6 && !plan.is_long))) return hipErrorInvalidValue;
   return launch_wave<float, GtopMmaState>(args, st, plan, dyn, stream);
 }
 

@@ -456,6 +456,11 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
  *       at the evaluation.
  *   6   five lanes per segment: two trajectories of up to 6 segments per
  *       wavefront, one of up to 12, or 12 segments at a time beyond that.
+ *   10  three lanes per segment, 21 / m whole trajectories per wavefront; up to
+ *       10 segments, plain evaluations; more: GTOP_ERR_INVALID at the
+ *       evaluation.  Five lanes per segment leave most of a wavefront idle for
+ *       every length but 6, 11 and 12 segments: the rule takes three for
+ *       2 .. 5 segments from 8 192 trajectories and for 7 .. 10 from 4 096.
  *   30  ONE lane per segment (a lane walks all 30 samples), 64 / m whole
  *       trajectories per wavefront; up to 12 segments, plain evaluations (the
  *       batched optimizer keeps its own rule); more segments: GTOP_ERR_INVALID

@@ -222,7 +222,7 @@ def test_dyn_feasibility_flag(scene, oracle_mod):
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("spl,B", [(0, 1), (3, 23), (3, 600), (3, 3101), (6, 23), (6, 600), (6, 9000), (0, 9000),
-                                   (30, 23), (30, 3101)])
+                                   (30, 23), (30, 3101), (10, 23), (10, 3101)])
 def test_dyn_feasibility_every_body(scene, oracle_mod, dtype, spl, B):
     """enable_dyn through every compiled DYN body (grad_traj_optimizer.cpp:383-407, :517-535): ten lanes per segment
     (one trajectory per wavefront), five lanes per segment with two trajectories per wavefront, in fp64 and fp32

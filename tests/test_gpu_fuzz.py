@@ -102,6 +102,8 @@ def test_random_draw_matches_the_oracle(gtop, oracle_mod, seed):
     ctx.set_params(**kw)
     if b.m <= 12 and seed % 5 == 0:       # a fifth of the draws of up to 12 segments: one lane per segment (what the
         ctx.set_launch_geometry(0, 30)    # launch rule itself takes only for very large fp32 batches)
+    elif b.m <= 10 and seed % 5 == 1:     # another fifth (up to 10 segments): three lanes per segment (the rule's choice for
+        ctx.set_launch_geometry(0, 10)    # large batches of every length but 6)
     # host entry point (gtop_set_problem + gtop_eval_batch)
     ctx.set_problem(b.T, b.Df)
     c, g = ctx.eval_batch(b.x)
@@ -141,6 +143,8 @@ def test_random_draw_fp32(gtop, oracle_mod, seed):
     xd, Dfd, Td = (torch.tensor(a, dtype=torch.float32, device=dev) for a in (x32, Df32.reshape(-1, 18), T32))
     if m <= 12 and seed % 3 == 0:         # a third of the draws of up to 12 segments: one lane per segment, 15 packed pairs
         ctx.set_launch_geometry(0, 30)
+    elif m <= 10 and seed % 3 == 1:       # another third (up to 10 segments): three lanes per segment, 5 packed pairs
+        ctx.set_launch_geometry(0, 10)
     cd, gd = ctx.eval_device(xd, Dfd, Td)
     torch.cuda.synchronize()
     # The bounds, each from the arithmetic.  Plain: TOL32 = 2e-4 (a gradient entry is a sum of 30 m samples' terms that

@@ -123,12 +123,13 @@ def test_fp64_parity_host_api(scene, oracle_mod, m, kw):
 
 
 @pytest.mark.parametrize("m", [2, 3, 4, 5, 6, 7, 12, 13, 24, 25, 37])
-@pytest.mark.parametrize("spl", [0, 3, 6])
+@pytest.mark.parametrize("spl", [0, 3, 6, 10, 30])
 @pytest.mark.parametrize("waves", [0, 1])
 def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, waves):
     """Samples per lane (ten or five lanes per segment, one or two trajectories per wavefront, two wavefronts per
-    trajectory, chunks of 12 segments past 12) only changes the work split.  Ten lanes per segment hold up to 6 segments
-    per wavefront, 12 on two: refused beyond."""
+    trajectory, chunks of 12 segments past 12; three lanes or one lane per segment with as many trajectories per
+    wavefront as fit) only changes the work split.  Ten lanes per segment hold up to 6 segments per wavefront, 12 on
+    two: refused beyond; three lanes per segment serve up to 10 segments, one lane up to 12."""
     mp, ctx, sdf = scene
     b = problem.make_trajectories(23, m, mp, seed=200 + m,    # odd: exercises a partial last pair / padding workgroups
                                   step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0))
@@ -137,7 +138,7 @@ def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, wave
     ctx.set_params(**kw)
     ctx.set_problem(b.T, b.Df)
     try:
-        if spl == 3 and m > 12:
+        if (spl == 3 and m > 12) or (spl == 10 and m > 10) or (spl == 30 and m > 12):
             with pytest.raises(gtop.GtopError) as e:
                 ctx.eval_batch(b.x)
             assert e.value.code == 1
@@ -151,11 +152,11 @@ def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, wave
 
 
 def test_launch_geometry_values(gtop):
-    """One kernel family: a workgroup is one wavefront; samples per lane 0, 3, 6 or 30."""
+    """One kernel family: a workgroup is one wavefront; samples per lane 0, 3, 6, 10 or 30."""
     ctx = gtop.GtopContext(device=0)
-    for waves, spl in ((0, 0), (1, 3), (1, 6), (0, 6), (0, 30)):
+    for waves, spl in ((0, 0), (1, 3), (1, 6), (0, 6), (0, 10), (0, 30)):
         ctx.set_launch_geometry(waves, spl)
-    for waves, spl in ((2, 3), (4, 0), (0, 1), (0, 5), (0, 15), (0, 10), (-1, 0)):
+    for waves, spl in ((2, 3), (4, 0), (0, 1), (0, 5), (0, 15), (0, 2), (-1, 0)):
         with pytest.raises(gtop.GtopError) as e:
             ctx.set_launch_geometry(waves, spl)
         assert e.value.code == 1
@@ -179,7 +180,7 @@ def test_parity_wide_index_field(gtop, oracle_mod):
     sdf = oracle_mod.Sdf(origin, res, grid, dist)
     ctx.set_params()
     ctx.set_problem(b.T, b.Df)
-    for spl in (3, 6, 30):
+    for spl in (3, 6, 10, 30):
         ctx.set_launch_geometry(0, spl)
         c, g = ctx.eval_batch(b.x)
         c_ref, g_ref, _ = oracle_mod.eval_batch(b.T, b.Df, b.x, sdf, oracle_mod.make_params())

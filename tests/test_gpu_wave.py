@@ -1,7 +1,8 @@
 """gtop_eval_wave_kernel (csrc/gtop_kernels.hip) through every instantiation: one trajectory of up
 to 6 segments per wavefront (samples per lane 3; latency variant below 3 072 trajectories, three-wavefront variant
-above), one of up to 12 or two of up to 6 (samples per lane 6), one lane per segment with 64 / m whole trajectories per
-wavefront (samples per lane 30), fp64 and fp32 (packed pairs at 6 and 30), odd batches (a partial last pair / group,
+above), one of up to 12 or two of up to 6 (samples per lane 6), three lanes per segment with 21 / m whole trajectories per
+wavefront (samples per lane 10), one lane per segment with 64 / m (samples per lane 30), fp64 and fp32 (packed pairs at 6,
+10 and 30), odd batches (a partial last pair / group,
 padding workgroups), the edge cases of the sample loop, and the collision-free instantiation."""
 import numpy as np
 import pytest
@@ -44,7 +45,8 @@ def _run(ctx, b, spl, dtype, **params):
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("spl,m", [(3, 2), (3, 3), (3, 5), (3, 6), (6, 5), (6, 6), (6, 7), (6, 9), (6, 11), (6, 12),
-                                   (30, 2), (30, 3), (30, 5), (30, 6), (30, 7), (30, 10), (30, 12)])
+                                   (30, 2), (30, 3), (30, 5), (30, 6), (30, 7), (30, 10), (30, 12),
+                                   (10, 2), (10, 3), (10, 4), (10, 5), (10, 6), (10, 7), (10, 8), (10, 10)])
 @pytest.mark.parametrize("B", [23, 3101])
 def test_every_instantiation(scene, oracle_mod, dtype, spl, m, B):
     mp, ctx, sdf = scene
@@ -59,7 +61,7 @@ def test_every_instantiation(scene, oracle_mod, dtype, spl, m, B):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("spl", [3, 6, 30])
+@pytest.mark.parametrize("spl", [3, 6, 10, 30])
 def test_edge_cases_of_the_sample_loop(scene, oracle_mod, dtype, spl):
     """Out-of-map samples (dist = -1, grad = 0), 29 / 20 / 0 / 30-sample segments (T = 0.03, 0.02, 0.0009, 0.031:
     the replay of `t += dt`, grad_traj_optimizer.cpp:353), together in one batch with ordinary rows."""
@@ -79,7 +81,7 @@ def test_edge_cases_of_the_sample_loop(scene, oracle_mod, dtype, spl):
 
 
 @pytest.mark.parametrize("kw", [dict(wc=0.0), dict(wc=5e-5), dict(step=1), dict(ws=0.0), dict(ws=20.0, wc=1.0)])
-@pytest.mark.parametrize("spl,m", [(3, 6), (6, 6), (6, 12), (3, 12), (3, 7), (30, 6), (30, 12), (30, 4)])
+@pytest.mark.parametrize("spl,m", [(3, 6), (6, 6), (6, 12), (3, 12), (3, 7), (30, 6), (30, 12), (30, 4), (10, 4), (10, 8)])
 def test_parameter_sets_and_the_collision_free_instantiation(scene, oracle_mod, spl, m, kw):
     """|wc| < 1e-4 skips the sample loop (:346: the COLLI = false instantiation); step 1 drops the jerk weight (:412-415,
     applied by the launcher)."""
@@ -121,7 +123,7 @@ def test_rows_do_not_depend_on_their_place(scene):
     in a full or a partial last pair, in the latency or the three-wavefront variant's batch."""
     mp, ctx, sdf = scene
     b = problem.make_trajectories(3101, 6, mp, seed=77)
-    for spl, dtype in ((3, "f64"), (6, "f64"), (6, "f32"), (30, "f64"), (30, "f32")):
+    for spl, dtype in ((3, "f64"), (6, "f64"), (6, "f32"), (30, "f64"), (30, "f32"), (10, "f64"), (10, "f32")):
         c, g = _run(ctx, b, spl, dtype)
         perm = np.random.default_rng(1).permutation(3101)
         cp, gp = _run(ctx, problem.permute(b, perm), spl, dtype)
@@ -180,7 +182,7 @@ np.savez(sys.argv[1], **out)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("spl", [3, 6, 30])
+@pytest.mark.parametrize("spl", [3, 6, 10, 30])
 def test_samples_past_the_loop_bound_cannot_overflow_into_the_sums(scene, oracle_mod, dtype, spl):
     """A 20 ms segment has 20 samples (`t += dt` up to T, src/grad_traj_optimizer.cpp:353); the lanes of the other ten
     evaluate too, with weight 0.  With the dyn block on and r_v just large enough for the reference's own samples
