@@ -109,6 +109,8 @@ def dominant_kernel(m, B, dtype, pinned):
     if pinned:
         return "gtop_eval_wave_kernel (pinned samples per lane)"
     tail = "(anonymous namespace)::GtopNoMma, false, "
+    if 12 < m <= 64 and ((64 // m) * ((m + 11) // 12) >= 5 or (m + 11) // 12 >= 4) and B >= 1024 * (64 // m):
+        return f"gtop_eval_wave_kernel<{R}, false, 30, 1, true, 3, {tail}false>"    # one lane per segment past 12 segments
     if dtype == "f32" and m <= 12 and B * m >= 65536 * 6:
         return f"gtop_eval_wave_kernel<{R}, false, 30, 1, true, 3, {tail}false>"    # one lane per segment, 64 / m trajectories per wavefront
     if m <= 10 and m != 6 and B >= (8192 if m <= 5 else 4096):

@@ -1554,7 +1554,7 @@ bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimize
   p.nw = 1;
   // one lane per segment (SPL = 30; the kernel's MANY): trajectories of up to 12 segments, 64 / m of them per wavefront,
   // plain evaluation only — for batches that put several such wavefronts on every SIMD
-  const bool many_ok = m <= 12 && !for_optimizer;
+  const bool many_ok = m <= 64 && !for_optimizer;   // (a wavefront has 64 segment slots)
   if (pinned_spl == 30 && !many_ok) return false;
   // three lanes per segment (SPL = 10): 21 segment slots per wavefront, 21 / m whole trajectories of up to 10 segments.
   // Five lanes per segment hold 12 slots — two trajectories of up to 6 segments or one of up to 12 — and leave most of a
@@ -1576,7 +1576,21 @@ bool gtop_eval_plan(int B, int m, size_t elem, int pinned_spl, bool for_optimize
     *plan = p;
     return true;
   }
-  if (many_ok && (pinned_spl == 30 || (pinned_spl == 0 && elem == 4 && (long long)B * m >= GTOP_ONE_LANE_F32_FROM_SEGMENTS))) {
+  // ... and past 12 segments (up to 64: a wavefront's segment slots) where the chunked body — 12 segments at a time at
+  // five lanes per segment — ends on a mostly idle chunk: 64 / m trajectories per wavefront against ceil(m / 12) chunks
+  // per trajectory.  Measured (one box, us, chunked | one lane per segment, fp64): B = 8 192 m = 13 56.0 | 34.7, 17 58.4 |
+  // 47.7, 22 58.8 | 61.8, 24 60.3 | 64.2, 25 83.4 | 70.5, 32 110 | 87.7, 33 110 | 109, 36 111 | 112; B = 4 096 m = 13
+  // 29.8 | 24.0, 17 31.5 | 32.4, 32 60.8 | 38.9, 40 90.3 | 61.1, 48 107 | 68.5, 64 192 | 87.6; B = 2 048 m = 13 15.5 | 19.6,
+  // 17 16.6 | 21.2, 32 39.4 | 25.5; fp32 B = 8 192 m = 13 43.9 | 23.6, 17 45.2 | 33.9, 24 46.1 | 43.0, 32 65.6 | 48.4, 36 66.1
+  // | 78.1.  So: when (trajectories per wavefront) x (chunks) >= 5, or from four chunks, and the batch gives every SIMD
+  // a wavefront.
+  bool many_long = false;
+  if (pinned_spl == 0 && many_ok && m > 12) {
+    const int nt30 = 64 / m, chunks = (m + 11) / 12;
+    many_long = (nt30 * chunks >= 5 || chunks >= 4) && B >= 1024 * nt30;
+  }
+  if (many_ok && (pinned_spl == 30 || many_long ||
+                  (pinned_spl == 0 && m <= 12 && elem == 4 && (long long)B * m >= GTOP_ONE_LANE_F32_FROM_SEGMENTS))) {
     p.spl = 30;
     p.nt = 64 / m;
     p.is_long = false;

@@ -462,11 +462,12 @@ int gtop_clear_cost_curve(gtop_ctx *ctx);
  *       every length but 6, 11 and 12 segments: the rule takes three for
  *       2 .. 5 segments from 8 192 trajectories and for 7 .. 10 from 4 096.
  *   30  ONE lane per segment (a lane walks all 30 samples), 64 / m whole
- *       trajectories per wavefront; up to 12 segments, plain evaluations (the
+ *       trajectories per wavefront; up to 64 segments, plain evaluations (the
  *       batched optimizer keeps its own rule); more segments: GTOP_ERR_INVALID
  *       at the evaluation.  Fewest instructions per trajectory, most distinct
  *       cache lines per load: the rule takes it for fp32 batches of 65 536
- *       six-segment trajectories and more.
+ *       six-segment trajectories and more, and past 12 segments wherever the
+ *       12-segments-at-a-time body would end on a mostly idle chunk.
  *   0   choose from B, m and dtype (measured rule).
  * Other values are GTOP_ERR_INVALID at the call.  Results do not depend on the
  * geometry beyond fp summation order. */

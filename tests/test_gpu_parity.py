@@ -129,7 +129,7 @@ def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, wave
     """Samples per lane (ten or five lanes per segment, one or two trajectories per wavefront, two wavefronts per
     trajectory, chunks of 12 segments past 12; three lanes or one lane per segment with as many trajectories per
     wavefront as fit) only changes the work split.  Ten lanes per segment hold up to 6 segments per wavefront, 12 on
-    two: refused beyond; three lanes per segment serve up to 10 segments, one lane up to 12."""
+    two: refused beyond; three lanes per segment serve up to 10 segments, one lane up to 64."""
     mp, ctx, sdf = scene
     b = problem.make_trajectories(23, m, mp, seed=200 + m,    # odd: exercises a partial last pair / padding workgroups
                                   step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0))
@@ -138,7 +138,7 @@ def test_fp64_parity_every_launch_geometry(scene, oracle_mod, gtop, m, spl, wave
     ctx.set_params(**kw)
     ctx.set_problem(b.T, b.Df)
     try:
-        if (spl == 3 and m > 12) or (spl == 10 and m > 10) or (spl == 30 and m > 12):
+        if (spl == 3 and m > 12) or (spl == 10 and m > 10) or (spl == 30 and m > 64):
             with pytest.raises(gtop.GtopError) as e:
                 ctx.eval_batch(b.x)
             assert e.value.code == 1

@@ -46,11 +46,13 @@ def _run(ctx, b, spl, dtype, **params):
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("spl,m", [(3, 2), (3, 3), (3, 5), (3, 6), (6, 5), (6, 6), (6, 7), (6, 9), (6, 11), (6, 12),
                                    (30, 2), (30, 3), (30, 5), (30, 6), (30, 7), (30, 10), (30, 12),
-                                   (10, 2), (10, 3), (10, 4), (10, 5), (10, 6), (10, 7), (10, 8), (10, 10)])
+                                   (10, 2), (10, 3), (10, 4), (10, 5), (10, 6), (10, 7), (10, 8), (10, 10),
+                                   (30, 13), (30, 17), (30, 22), (30, 33), (30, 64)])
 @pytest.mark.parametrize("B", [23, 3101])
 def test_every_instantiation(scene, oracle_mod, dtype, spl, m, B):
     mp, ctx, sdf = scene
-    b = problem.make_trajectories(B, m, mp, seed=600 + 13 * m + spl, step_len=(0.5, 1.2) if m > 6 else (1.0, 2.0))
+    b = problem.make_trajectories(B, m, mp, seed=600 + 13 * m + spl,
+                                  step_len=(0.2, 0.5) if m > 12 else (0.5, 1.2) if m > 6 else (1.0, 2.0))
     c, g = _run(ctx, b, spl, dtype)
     idx = np.arange(B) if B <= 64 else np.r_[0:40, B - 40:B]          # both ends: the last pair / padding workgroups
     c_ref, g_ref, _ = oracle_mod.eval_batch(b.T[idx], b.Df[idx], b.x[idx], sdf, oracle_mod.make_params(), nthreads=8)
