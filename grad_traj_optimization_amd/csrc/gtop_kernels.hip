@@ -15,9 +15,11 @@
 // waypoints s and s+1, and d'Rd = sum_s c_s' Q_s c_s.  The kernel therefore
 // takes (x, Df, T) and works per segment.  ONE kernel family serves every
 // launch, gtop_eval_wave_kernel: a wavefront owns one or two
-// whole trajectories, a segment is sampled by LPS = 30/SPL adjacent lanes with
-// SPL samples each (SPL = 3: ten lanes, up to 6 segments; SPL = 6: five lanes,
-// up to 12 segments at a time), and the evaluation is one dependent chain:
+// whole trajectories — or as many as fit —, a segment is sampled by LPS = 30/SPL
+// adjacent lanes with SPL samples each (SPL = 3: ten lanes, up to 6 segments;
+// SPL = 6: five lanes, up to 12 segments at a time; SPL = 10 / 30: three lanes /
+// one lane, 21 / 64 segment slots shared by 21/m / 64/m trajectories), and the
+// evaluation is one dependent chain:
 //   * every lane of a segment forms the segment's 18 polynomial coefficients
 //     c_{s,k} = A_s^-1 d_{s,k} in registers;
 //   * per sample: position/velocity (float round trip), trilinear field lookup
