@@ -210,3 +210,20 @@ def test_samples_past_the_loop_bound_cannot_overflow_into_the_sums(scene, oracle
     rc, rg = scenes.rel_err(c, g, c_ref, g_ref)
     tol = TOL64 if dtype == "f64" else 2e-2           # (fp32: exp(80) turns the velocity's rounding into 1e-3 and more)
     assert rc <= tol and rg <= tol, (rc, rg)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("m,B", [(3, 8200), (8, 4100), (13, 4100), (24, 2100), (40, 1030), (64, 1025), (65, 300)])
+def test_the_launch_rule_left_to_itself_past_its_switch_points(scene, oracle_mod, dtype, m, B):
+    """Batches just past the switch points of gtop_eval_plan, nothing pinned: three lanes per segment (3 and 8 segments),
+    one lane per segment (13, 40, 64), the chunked body where that one stays ahead (24) or has to (65) — against the
+    oracle on both ends of the batch (the last, partly filled wavefront included)."""
+    mp, ctx, sdf = scene
+    b = problem.make_trajectories(B, m, mp, seed=4000 + m, step_len=(0.2, 0.5) if m > 12 else (0.5, 1.2) if m > 6 else (1.0, 2.0))
+    c, g = _run(ctx, b, 0, dtype)
+    idx = np.r_[0:24, B - 24:B]
+    c_ref, g_ref, _ = oracle_mod.eval_batch(b.T[idx], b.Df[idx], b.x[idx], sdf, oracle_mod.make_params(), nthreads=8)
+    rc, rg = scenes.rel_err(c[idx], g[idx], c_ref, g_ref)
+    tol = TOL64 if dtype == "f64" else TOL32 * (3 if m > 12 else 1)      # (fp32: long chains of short segments, as in test_gpu_kino)
+    assert rc <= tol and rg <= tol, (rc, rg)
+    assert np.isfinite(c).all() and np.isfinite(g).all()
