@@ -794,6 +794,13 @@ def extras(args, ctx, batch, mp, osdf, oracle, x, Df, T, tdtype, dev):
             out["workloads"].append(_extra_workload(
                 ctx, oracle, osdf, big, 6, 200, name, dev,
                 f"B=16384 x 6 segments, 200^3 SDF, {name}" + (" [BASELINE.json configs[2]]" if name == "f32" else "")))
+        # the reference's own scene length (opti_node.cpp:61-99: 11 waypoints, 10 segments) as a batch: three lanes per
+        # segment, two whole trajectories per wavefront (60 busy lanes; five lanes per segment: 50)
+        ten = problem.make_trajectories(8192, 10, mp, seed=9, step_len=(0.5, 1.2))
+        ten = problem.permute(ten, problem.spatial_order(ten.waypoints, mp.origin, mp.map_size))
+        out["workloads"].append(_extra_workload(ctx, oracle, osdf, ten, 10, 200, "f64", dev,
+                                                "B=8192 x 10 segments (the reference scene's length), 200^3 SDF, f64"))
+        del ten
         # configs[4]: 8 192 trajectories x 40 control points (m = 12), 400^3 field of mixed obstacle density
         t0 = time.time()
         mp4 = problem.make_map(400, density=0.04, seed=2)
