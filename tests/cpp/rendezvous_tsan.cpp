@@ -158,8 +158,13 @@ void scenario_misuse() {
   EXPECT(gtop_cost_nlopt_shared(kN + 1, x.data(), nullptr, gtop_rendezvous_get_slot(r, 0)) == HUGE_VAL);   // wrong n
   EXPECT(gtop_rendezvous_get_slot(r, 2) == nullptr);
   // a leave from another thread while the slot's own caller is blocked inside the callback is refused
-  std::thread blocked([&] { (void)gtop_cost_nlopt_shared(kN, x.data(), nullptr, gtop_rendezvous_get_slot(r, 0)); });
-  std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  std::atomic<bool> entering{false};
+  std::thread blocked([&] {
+    entering.store(true);
+    (void)gtop_cost_nlopt_shared(kN, x.data(), nullptr, gtop_rendezvous_get_slot(r, 0));
+  });
+  while (!entering.load()) std::this_thread::yield();
+  std::this_thread::sleep_for(std::chrono::milliseconds(100));   // (the call is a few instructions behind the flag; generous for a loaded machine)
   EXPECT(gtop_rendezvous_leave(gtop_rendezvous_get_slot(r, 0)) == GTOP_ERR_STATE);
   EXPECT(gtop_rendezvous_leave(gtop_rendezvous_get_slot(r, 1)) == GTOP_OK);   // the other one leaves: slot 0 is evaluated
   blocked.join();
