@@ -110,3 +110,18 @@ def test_eigen_adapter_header_says_what_it_needs(tmp_path):
                          *inc, str(src)], capture_output=True, text=True)
     assert ok.returncode == 0, ok.stderr
     assert os.path.exists(os.path.join(ROOT, "grad_traj_optimization_amd", "gtop_eigen_adapter"))
+
+
+def test_reciprocal_divisions_of_the_per_wavefront_task_lists_are_exact():
+    """csrc/gtop_kernels.hip, the geometries with 21 / m or 64 / m trajectories per wavefront: a lane's trajectory is
+    slot / m by a 16-bit reciprocal and a task's trajectory qi / n by a 24-bit one (no integer division in the kernel).
+    Exhaustively, for every segment count and every index the kernel can form: the same as floor division, and the
+    product stays inside 32 bits."""
+    for slots in (64, 21):
+        for m in range(2, slots + 1):
+            inv = (65536 + m - 1) // m
+            assert all(((slot * inv) >> 16) == slot // m for slot in range(64))
+            n, nt = 9 * (m - 1), slots // m
+            inv_n = ((1 << 24) + n - 1) // n
+            for qi in range(nt * n):
+                assert qi * inv_n < 2 ** 32 and ((qi * inv_n) >> 24) == qi // n
