@@ -505,8 +505,15 @@ static int update_window_on_stream(gtop_ctx *c, const double min_pos[3], const d
   const bool whole = !empty && lo[0] == 0 && lo[1] == 0 && lo[2] == 0 && hi[0] == g.nx - 1 && hi[1] == g.ny - 1 && hi[2] == g.nz - 1;
   if (whole)   // the window is the map: the whole-grid builder (same results: every distance is 10000 after the reset)
     return update_sdf_map_on_stream(c, d_pts, npts, s, convert_now);
-  HIPCHK(c, gtop_launch_esdf_window_reset(g, lo, hi, c->occ, c->sdf64, s));
-  HIPCHK(c, gtop_launch_esdf_mark(g, d_pts, npts, c->occ, s));   // (anywhere in the map: setOccupancy does not look at the window)
+  // (the compact path — see below — resets and marks on its own)
+  const int cwx = hi[0] - lo[0] + 1, cwy = hi[1] - lo[1] + 1, cwz = hi[2] - lo[2] + 1;
+  GtopGrid csub = g;
+  csub.nx = cwx; csub.ny = cwy; csub.nz = cwz;
+  const bool compact = !empty && cwx >= 12 && cwy >= 12 && cwz >= 3 && gtop_esdf_supported(csub);
+  if (!compact) {
+    HIPCHK(c, gtop_launch_esdf_window_reset(g, lo, hi, c->occ, c->sdf64, s));
+    HIPCHK(c, gtop_launch_esdf_mark(g, d_pts, npts, c->occ, s));   // (anywhere in the map: setOccupancy does not look at the window)
+  }
   if (empty) return GTOP_OK;
   // The sweeps over the window see nothing outside it: the update IS the whole-grid transform of the window taken alone.
   // A window of at least 12 x 12 x 3 voxels therefore goes through the whole-grid builder (gtop_esdf.hip: packed 16-bit
@@ -515,8 +522,11 @@ static int update_window_on_stream(gtop_ctx *c, const double min_pos[3], const d
   const int wx = hi[0] - lo[0] + 1, wy = hi[1] - lo[1] + 1, wz = hi[2] - lo[2] + 1;
   GtopGrid sub = g;
   sub.nx = wx; sub.ny = wy; sub.nz = wz;
-  if (wx >= 12 && wy >= 12 && wz >= 3 && gtop_esdf_supported(sub)) {
-    HIPCHK(c, gtop_launch_esdf_window_gather(g, lo, hi, c->occ, c->win_occ, s));
+  if (compact) {
+    // reset + marking of the map's occupancy and of the compact copy in two kernels, no gather; the window's distances
+    // need no reset: the scatter below rewrites every voxel of it
+    (void)wx; (void)wy; (void)wz;
+    HIPCHK(c, gtop_launch_esdf_window_reset_mark_compact(g, lo, hi, d_pts, npts, c->occ, c->win_occ, s));
     HIPCHK(c, gtop_launch_esdf_build(sub, c->win_occ, c->tmp1, c->tmp2, c->rows, c->win_dist, nullptr, s));
     HIPCHK(c, gtop_launch_esdf_window_scatter(g, lo, hi, c->win_dist, c->sdf64, s));
   } else {

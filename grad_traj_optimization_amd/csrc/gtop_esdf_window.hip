@@ -122,6 +122,37 @@ window_gather_kernel(const GtopGrid g, const Window w, const uint8_t *__restrict
   sub[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = occ[idx];
 }
 
+// The compact path's reset and marking in one pass each (no gather): the window's occupancy is cleared in the map AND in
+// the compact copy (the distances need no reset there: the scatter rewrites every voxel of the window), and a point is
+// marked in the map wherever it falls (setOccupancy, sdf_map.cpp:80-99) and in the compact copy when it falls inside.
+__global__ void __launch_bounds__(256)
+window_reset_compact_kernel(const GtopGrid g, const Window w, uint8_t *__restrict__ occ, uint8_t *__restrict__ sub) {
+  int x, y, z;
+  size_t idx;
+  if (!window_voxel(g, w, x, y, z, idx)) return;
+  occ[idx] = 0;
+  sub[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = 0;
+}
+
+__global__ void __launch_bounds__(256)
+window_mark_kernel(const GtopGrid g, const Window w, const double *__restrict__ pts, int npts, uint8_t *__restrict__ occ,
+                   uint8_t *__restrict__ sub) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npts) return;
+  const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  for (int k = 0; k < 3; ++k)   // isInMap, sdf_map.cpp:55-69
+    if (p[k] < g.min_range[k] + 1e-4 || p[k] > g.max_range[k] - 1e-4) return;
+  const int ix = (int)floor((p[0] - g.origin[0]) * g.res_inv);   // posToIndex, sdf_map.cpp:71-74
+  const int iy = (int)floor((p[1] - g.origin[1]) * g.res_inv);
+  const int iz = (int)floor((p[2] - g.origin[2]) * g.res_inv);
+  if (ix < 0 || iy < 0 || iz < 0 || ix >= g.nx || iy >= g.ny || iz >= g.nz) return;  // memory safety only
+  occ[((size_t)ix * g.ny + iy) * g.nz + iz] = 1;   // sdf_map.cpp:97-98
+  if (ix >= w.lo[0] && ix <= w.hi[0] && iy >= w.lo[1] && iy <= w.hi[1] && iz >= w.lo[2] && iz <= w.hi[2]) {
+    const int wz = w.hi[2] - w.lo[2] + 1, wy = w.hi[1] - w.lo[1] + 1;
+    sub[((size_t)(ix - w.lo[0]) * wy + (iy - w.lo[1])) * wz + (iz - w.lo[2])] = 1;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 window_scatter_kernel(const GtopGrid g, const Window w, const double *__restrict__ sub, double *__restrict__ dist) {
   int x, y, z;
@@ -138,6 +169,18 @@ hipError_t gtop_launch_esdf_window_gather(const GtopGrid &g, const int lo[3], co
   Window w{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
   const long long n = (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
   hipLaunchKernelGGL(window_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, w, occ, sub);
+  return hipGetLastError();
+}
+
+// reset + mark of the compact path (see the kernels): occupancy of the map and of the compact copy `sub`, no gather
+hipError_t gtop_launch_esdf_window_reset_mark_compact(const GtopGrid &g, const int lo[3], const int hi[3], const double *pts,
+                                                      int npts, uint8_t *occ, uint8_t *sub, hipStream_t stream) {
+  Window w{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+  const long long n = (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+  hipLaunchKernelGGL(window_reset_compact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, w, occ, sub);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || npts <= 0) return e;
+  hipLaunchKernelGGL(window_mark_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, stream, g, w, pts, npts, occ, sub);
   return hipGetLastError();
 }
 

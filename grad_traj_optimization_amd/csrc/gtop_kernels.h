@@ -117,6 +117,10 @@ hipError_t gtop_launch_esdf_window_gather(const GtopGrid &g, const int lo[3], co
                                           uint8_t *sub, hipStream_t stream);
 hipError_t gtop_launch_esdf_window_scatter(const GtopGrid &g, const int lo[3], const int hi[3], const double *sub,
                                            double *dist, hipStream_t stream);
+// the compact path's reset + marking without a gather: clears the window's occupancy in the map and in `sub`, marks the
+// points in the map and (inside the window) in `sub`; the distances are not reset (the scatter rewrites the window)
+hipError_t gtop_launch_esdf_window_reset_mark_compact(const GtopGrid &g, const int lo[3], const int hi[3], const double *pts,
+                                                      int npts, uint8_t *occ, uint8_t *sub, hipStream_t stream);
 
 // ---- corner records (gtop_records.hip): the gather-friendly resident copy the lookups read ----
 size_t gtop_record_count(const GtopGrid &g);   // (nx+1)(ny+1)(nz+2) records of 4 values
