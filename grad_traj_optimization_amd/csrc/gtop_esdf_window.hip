@@ -14,9 +14,9 @@
 // reference's lower-envelope pass (fillESDF, :266-308) finds; on this data every quantity is an exact integer, so the
 // kernels take that minimum directly in int32 with an INF sentinel (see gtop_esdf.hip, whose whole-grid kernels this
 // file's full-window case hands over to).  Because the sweeps never look outside the window, the update IS the
-// whole-grid transform of the window taken alone: gtop_capi.cpp gathers the occupancy of a window of at least
-// 12 x 12 x 3 voxels into a compact grid (window_gather_kernel), runs gtop_esdf.hip's builder on it and writes the
-// result back (window_scatter_kernel).  The plain kernels below — one lane per voxel of the window, lanes along z: the
+// whole-grid transform of the window taken alone: for a window of at least 12 x 12 x 3 voxels gtop_capi.cpp keeps its
+// occupancy as a compact grid beside the map's (window_reset_compact_kernel, window_mark_kernel), runs gtop_esdf.hip's
+// builder on it and writes the result back (window_scatter_kernel).  The plain kernels below — one lane per voxel of the window, lanes along z: the
 // nearest occupied voxel of the column by an outward walk, then two outward scans with the exact cut-off
 // d^2 >= best — serve the slivers (10x the time per voxel: no packed 16-bit scans, candidate lists or slab skipping).
 #include <hip/hip_runtime.h>
@@ -114,15 +114,7 @@ window_scan_kernel(const GtopGrid g, const Window w, const int *__restrict__ in,
 // The window's occupancy as a compact grid of its own, and the compact grid's distances back into the window: a
 // windowed update IS the whole-grid transform of the window taken alone (its sweeps never look outside it), so windows
 // that are large enough go through gtop_esdf.hip's optimised builder on the compact copy.
-__global__ void __launch_bounds__(256)
-window_gather_kernel(const GtopGrid g, const Window w, const uint8_t *__restrict__ occ, uint8_t *__restrict__ sub) {
-  int x, y, z;
-  size_t idx;
-  if (!window_voxel(g, w, x, y, z, idx)) return;
-  sub[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = occ[idx];
-}
-
-// The compact path's reset and marking in one pass each (no gather): the window's occupancy is cleared in the map AND in
+// Its reset and marking in one pass each (no gather pass over the window): the window's occupancy is cleared in the map AND in
 // the compact copy (the distances need no reset there: the scatter rewrites every voxel of the window), and a point is
 // marked in the map wherever it falls (setOccupancy, sdf_map.cpp:80-99) and in the compact copy when it falls inside.
 __global__ void __launch_bounds__(256)
@@ -163,14 +155,6 @@ window_scatter_kernel(const GtopGrid g, const Window w, const double *__restrict
 }
 
 }  // namespace
-
-hipError_t gtop_launch_esdf_window_gather(const GtopGrid &g, const int lo[3], const int hi[3], const uint8_t *occ,
-                                          uint8_t *sub, hipStream_t stream) {
-  Window w{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
-  const long long n = (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
-  hipLaunchKernelGGL(window_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, w, occ, sub);
-  return hipGetLastError();
-}
 
 // reset + mark of the compact path (see the kernels): occupancy of the map and of the compact copy `sub`, no gather
 hipError_t gtop_launch_esdf_window_reset_mark_compact(const GtopGrid &g, const int lo[3], const int hi[3], const double *pts,

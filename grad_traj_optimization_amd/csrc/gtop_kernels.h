@@ -112,9 +112,7 @@ hipError_t gtop_launch_esdf_window_reset(const GtopGrid &g, const int lo[3], con
                                          hipStream_t stream);
 hipError_t gtop_launch_esdf_window_build(const GtopGrid &g, const int lo[3], const int hi[3], const uint8_t *occ, int *tmp1,
                                          int *tmp2, double *dist, hipStream_t stream);
-// the window's occupancy as a compact grid (z fastest) / a compact grid's distances into the window
-hipError_t gtop_launch_esdf_window_gather(const GtopGrid &g, const int lo[3], const int hi[3], const uint8_t *occ,
-                                          uint8_t *sub, hipStream_t stream);
+// a compact grid's distances (z fastest) into the window
 hipError_t gtop_launch_esdf_window_scatter(const GtopGrid &g, const int lo[3], const int hi[3], const double *sub,
                                            double *dist, hipStream_t stream);
 // the compact path's reset + marking without a gather: clears the window's occupancy in the map and in `sub`, marks the
